@@ -1,0 +1,99 @@
+"""ctypes binding of libcpnative.so (include/cpnative.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or a call
+fails, an exception is raised (the product path must never silently run anything
+but the gfx950 kernels).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpnative.so")
+
+CP_F32, CP_BF16 = 0, 1
+CP_TASKS, CP_EMG_DIM, CP_D_E, CP_N_BN, CP_N_FC = 41, 12, 16, 9, 7
+
+_fp = C.c_void_p
+
+
+class cp_params(C.Structure):
+    _fields_ = [
+        ("conv1_w", _fp), ("conv1_b", _fp), ("conv2_w", _fp), ("conv2_b", _fp),
+        ("fc_w", _fp * CP_N_FC), ("fc_b", _fp * CP_N_FC),
+        ("bn_g", _fp * CP_N_BN), ("bn_b", _fp * CP_N_BN),
+        ("last_w", _fp), ("easy_w", _fp), ("easy_b", _fp),
+    ]
+
+
+class cp_bn_buffers(C.Structure):
+    _fields_ = [("running_mean", _fp * CP_N_BN), ("running_var", _fp * CP_N_BN)]
+
+
+class cp_config(C.Structure):
+    _fields_ = [
+        ("n_windows", C.c_int64), ("dtype", C.c_int32), ("adabn", C.c_int32),
+        ("training", C.c_int32), ("reserved", C.c_int32),
+        ("dp_emg", C.c_float), ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("reserved2", C.c_float),
+        ("seed", C.c_uint64), ("step", C.c_uint64),
+    ]
+
+
+class cp_adam_hyper(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("lr_emg", "lr_glove", "reg_emg", "reg_glove", "beta1", "beta2", "eps", "grad_scale")]
+
+
+# every symbol include/cpnative.h declares: (restype, argtypes)
+_P = C.POINTER
+SYMBOLS = {
+    "cp_version": (C.c_int, []),
+    "cp_last_error": (C.c_char_p, []),
+    "cp_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_float]),
+    "cp_gather_groups": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, C.c_int32, _fp, _fp]),
+    "cp_encoder_forward": (C.c_int, [_P(cp_config), _P(cp_params), _P(cp_bn_buffers), _fp, _fp, C.c_size_t, _fp, _fp]),
+    "cp_head": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t,
+                          _fp, _fp, _fp, _P(cp_params), _fp]),
+    "cp_encoder_backward": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, _P(cp_params), _fp]),
+    "cp_vote": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp]),
+    "cp_optimizer_scratch_floats": (C.c_size_t, [_P(C.c_int64), C.c_int32]),
+    "cp_l2_norms": (C.c_int, [_fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32), C.c_int32,
+                              _P(cp_adam_hyper), _fp, _fp, _fp]),
+    "cp_l2_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32),
+                                  C.c_int32, _P(cp_adam_hyper), C.c_int64, _fp, _fp, _fp]),
+    "cp_debug_activation": (C.c_int, [_P(cp_config), _fp, C.c_size_t, C.c_int32, _fp, _fp]),
+    "cp_debug_bn_stats": (C.c_int, [_P(cp_config), _fp, C.c_size_t, C.c_int32, _fp, _fp]),
+}
+
+_lib = None
+
+
+class CpNativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcpnative.so (built by ``__graft_entry__.build()`` / ``csrc/Makefile``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CpNativeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cp_version() < 100:
+        raise CpNativeError("libcpnative.so is older than this binding")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().cp_last_error().decode("utf-8", "replace")
+        raise CpNativeError(f"{what} failed: {msg}")

@@ -1,0 +1,523 @@
+// C ABI (include/cpnative.h) and the host-side sequencing of the contrastive step.
+// One enqueue-only function per stage; no allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+
+#include "../../include/cpnative.h"
+#include "common.cuh"
+#include "gemm_nt.cuh"
+#include "gemm_tn.cuh"
+#include "kernels_misc.cuh"
+#include "head.cuh"
+#include "optim.cuh"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s (code %d%s%s)", what, code, code < 10000 ? ": " : "",
+             code < 10000 ? hipGetErrorString((hipError_t)code) : "");
+    return code;
+}
+#define CK(expr)                                         \
+    do {                                                 \
+        hipError_t e_ = (expr);                          \
+        if (e_ != hipSuccess) return fail((int)e_, #expr); \
+    } while (0)
+#define CKL(what)                                        \
+    do {                                                 \
+        hipError_t e_ = hipGetLastError();               \
+        if (e_ != hipSuccess) return fail((int)e_, what); \
+    } while (0)
+
+extern "C" int cp_version(void) { return CP_VERSION; }
+extern "C" const char* cp_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------------------
+static const int kLayerC[CP_N_BN] = {64, 64, 512, 512, 512, 512, 512, 512, 512};
+static inline int fcK(int i) { return i == 0 ? 768 : 512; }
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WS {
+    size_t act[CP_N_BN];     // post-ReLU outputs, T
+    size_t u[4];             // dropout(BN(.)) of fc4..fc7, T (only when dp > 0)
+    size_t gbuf[2];          // gradient ping-pong, T [N][768]
+    size_t dz;               // [N][64] T
+    size_t partials;         // f32
+    size_t stats[CP_N_BN];   // [4][C] f32
+    size_t coef;             // [3][512] f32
+    size_t wc2_f, wc2_d;     // conv2 weights, T [64][192]
+    size_t wfc[CP_N_FC], bfc[CP_N_FC], wfc_t[CP_N_FC];
+    size_t wlast, blast, wlast_t, dzsum;
+    size_t slabs;            // f32
+    size_t head_part;        // f32
+    size_t total;
+    size_t partials_floats, slabs_floats;
+};
+static const size_t kSlabFloats = (size_t)32 * 512 * 768;
+static const int kHeadBlocksMax = 1024;
+
+static WS carve(int64_t N, int dtype, float dp) {
+    WS w;
+    const size_t es = dtype == CP_BF16 ? 2 : 4;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    for (int l = 0; l < CP_N_BN; ++l) w.act[l] = take((size_t)N * (l < 2 ? 768 : 512) * es);
+    for (int i = 0; i < 4; ++i) w.u[i] = dp > 0.f ? take((size_t)N * 512 * es) : 0;
+    for (int i = 0; i < 2; ++i) w.gbuf[i] = take((size_t)N * 768 * es);
+    w.dz = take((size_t)N * 64 * es);
+    w.partials_floats = (size_t)12 * N + 4 * 1024 * 1024;
+    w.partials = take(w.partials_floats * 4);
+    for (int l = 0; l < CP_N_BN; ++l) w.stats[l] = take(4 * 512 * 4);
+    w.coef = take(3 * 512 * 4);
+    w.wc2_f = take(64 * 192 * es);
+    w.wc2_d = take(64 * 192 * es);
+    for (int i = 0; i < CP_N_FC; ++i) {
+        w.wfc[i] = take((size_t)512 * fcK(i) * es);
+        w.bfc[i] = take(512 * 4);
+        w.wfc_t[i] = take((size_t)512 * fcK(i) * es);
+    }
+    w.wlast = take(32 * 512 * es);
+    w.blast = take(32 * 4);
+    w.wlast_t = take(512 * 64 * es);
+    w.dzsum = take(64 * 4);
+    w.slabs_floats = kSlabFloats;
+    w.slabs = take(kSlabFloats * 4);
+    w.head_part = take((size_t)kHeadBlocksMax * HEAD_PART * 4);
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t cp_workspace_bytes(int64_t max_windows, int32_t dtype, float dp_emg) {
+    if (max_windows <= 0) return 0;
+    return carve(max_windows, dtype, dp_emg).total;
+}
+
+static uint32_t host_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+static uint32_t dp_key(const cp_config* c, int layer) {
+    return host_hash32((uint32_t)c->seed ^ host_hash32((uint32_t)(c->seed >> 32) + 0x51ed27U) ^
+                       host_hash32((uint32_t)c->step * 0x9E3779B1U + (uint32_t)layer * 0x85EBCA77U +
+                                   (uint32_t)(c->step >> 32)));
+}
+static uint32_t dp_thresh(float p) {
+    double t = (double)p * 65536.0 + 0.5;
+    if (t < 1.0) t = 1.0;
+    if (t > 65535.0) t = 65535.0;
+    return (uint32_t)t;
+}
+static float dp_inv_keep(float p) { return 1.0f / (1.0f - (float)dp_thresh(p) / 65536.0f); }
+
+static int check_cfg(const cp_config* c, void* ws, size_t ws_bytes, WS* out) {
+    if (!c || !ws) return fail(CP_ERR_ARG, "null config/workspace");
+    if (c->n_windows <= 0 || c->n_windows % CP_TASKS != 0) return fail(CP_ERR_ARG, "n_windows must be a positive multiple of 41");
+    if (c->dtype != CP_F32 && c->dtype != CP_BF16) return fail(CP_ERR_ARG, "dtype");
+    if (c->dp_emg < 0.f || c->dp_emg >= 1.f) return fail(CP_ERR_ARG, "dp_emg");
+    *out = carve(c->n_windows, c->dtype, c->dp_emg);
+    if (out->total > ws_bytes) return fail(CP_ERR_WORKSPACE, "workspace too small");
+    if (((uintptr_t)ws & 255) != 0) return fail(CP_ERR_ARG, "workspace must be 256-byte aligned");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// gather
+// ---------------------------------------------------------------------------------------
+extern "C" int cp_gather_groups(const float* table, int64_t table_rows, const int64_t* emg_rand, int64_t D,
+                                const int64_t* perm, int64_t B, int32_t V, float* x_out, void* stream) {
+    if (!table || !emg_rand || !perm || !x_out || B <= 0 || V <= 0) return fail(CP_ERR_ARG, "cp_gather_groups args");
+    const int64_t total = B * CP_TASKS * V * 3;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(gather_groups_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, table, emg_rand, perm, x_out,
+                       B, CP_TASKS, (int)V, D, table_rows);
+    CKL("gather_groups_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// encoder forward
+// ---------------------------------------------------------------------------------------
+static inline int grid_rows(int64_t rows, int rows_per_block, int cap) {
+    int64_t g = (rows + rows_per_block - 1) / rows_per_block;
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+template <typename T>
+static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn_buffers* bn, const float* x,
+                             unsigned char* base, const WS& w, float* z, hipStream_t st) {
+    using D = DT<T>;
+    const int64_t N = c->n_windows, R12 = N * 12;
+    const bool batch_stats = c->training || c->adabn;
+    const bool have_running = bn && bn->running_mean[0] && bn->running_var[0];
+    if (!batch_stats && !have_running) return fail(CP_ERR_ARG, "eval with stock BN needs running statistics");
+    const int upd = (c->training && !c->adabn && have_running) ? 1 : 0;
+    const bool drop = c->training && c->dp_emg > 0.f;
+    float* partials = (float*)(base + w.partials);
+    auto act = [&](int l) { return (T*)(base + w.act[l]); };
+    auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
+    auto finalize = [&](int l, int nrows, double count) -> int {
+        const int C = kLayerC[l];
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(256), 0, st, partials, nrows, count, p->bn_g[l], p->bn_b[l],
+                           have_running ? bn->running_mean[l] : nullptr, have_running ? bn->running_var[l] : nullptr, upd,
+                           batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats(l), C);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail((int)e, "bn_finalize_kernel");
+    };
+
+    hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
+    CKL("prep_conv2_kernel");
+    // conv1
+    {
+        constexpr int RPP = 256 / (64 / D::EPC);
+        const int g = grid_rows(R12, RPP, 2048);
+        hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, act(0), partials, R12);
+        CKL("conv1_fwd_kernel");
+        if (int e = finalize(0, g, (double)R12)) return e;
+    }
+    // conv2
+    {
+        GemmNTArgs a{};
+        a.A = act(0); a.lda = 64; a.M = R12; a.K = 192;
+        a.W = base + w.wc2_f; a.F = 64;
+        a.C = act(1); a.ldc = 64; a.bias = p->conv2_b; a.relu = 1;
+        a.partials = partials; a.a_scale = stats(0) + 2 * 64; a.a_shift = stats(0) + 3 * 64;
+        CK((launch_gemm_nt<T, 128, 64, ALOAD_CONV, EPI_FWD>(a, st)));
+        if (int e = finalize(1, (int)((R12 + 127) / 128), (double)R12)) return e;
+    }
+    // fc1..fc7
+    for (int i = 0; i < CP_N_FC; ++i) {
+        const int L = 2 + i, Lp = L - 1, K = fcK(i);
+        const T* A = act(Lp);
+        const float *s = stats(Lp) + 2 * kLayerC[Lp], *t = stats(Lp) + 3 * kLayerC[Lp];
+        if (drop && Lp >= 5) {
+            T* u = (T*)(base + w.u[Lp - 5]);
+            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N * 512 / D::EPC, 256, 4096)), dim3(256), 0, st,
+                               act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg));
+            CKL("bn_dropout_apply_kernel");
+            A = u; s = nullptr; t = nullptr;
+        }
+        hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(512), dim3(256), 0, st, p->fc_w[i], p->fc_b[i], s, t,
+                           (T*)(base + w.wfc[i]), (float*)(base + w.bfc[i]), 512, K, i == 0 ? 1 : 0);
+        CKL("fold_linear_kernel");
+        GemmNTArgs a{};
+        a.A = A; a.lda = K; a.M = N; a.K = K;
+        a.W = base + w.wfc[i]; a.F = 512;
+        a.C = act(L); a.ldc = 512; a.bias = (float*)(base + w.bfc[i]); a.relu = 1;
+        a.partials = partials;
+        CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_FWD>(a, st)));
+        if (int e = finalize(L, (int)((N + 127) / 128), (double)N)) return e;
+    }
+    // projection 512 -> 16 (weights padded to 32 rows)
+    {
+        const int Lp = 8;
+        const T* A = act(Lp);
+        const float *s = stats(Lp) + 2 * 512, *t = stats(Lp) + 3 * 512;
+        if (drop) {
+            T* u = (T*)(base + w.u[Lp - 5]);
+            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N * 512 / D::EPC, 256, 4096)), dim3(256), 0, st,
+                               act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg));
+            CKL("bn_dropout_apply_kernel");
+            A = u; s = nullptr; t = nullptr;
+        }
+        hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(32), dim3(256), 0, st, p->last_w, (const float*)nullptr, s, t,
+                           (T*)(base + w.wlast), (float*)(base + w.blast), CP_D_E, 512, 0);
+        CKL("fold_linear_kernel(last)");
+        GemmNTArgs a{};
+        a.A = A; a.lda = 512; a.M = N; a.K = 512;
+        a.W = base + w.wlast; a.F = 32;
+        a.C = z; a.ldc = CP_D_E; a.f_valid = CP_D_E; a.bias = (float*)(base + w.blast);
+        CK((launch_gemm_nt<T, 128, 32, ALOAD_PLAIN, EPI_PLAIN_F32>(a, st)));
+    }
+    return 0;
+}
+
+extern "C" int cp_encoder_forward(const cp_config* cfg, const cp_params* p, const cp_bn_buffers* bn, const float* x,
+                                  void* ws, size_t ws_bytes, float* z_out, void* stream) {
+    WS w;
+    if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
+    if (!p || !x || !z_out) return fail(CP_ERR_ARG, "cp_encoder_forward args");
+    if (cfg->dtype == CP_BF16)
+        return encoder_forward_t<bf16_t>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
+    return encoder_forward_t<float>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// head
+// ---------------------------------------------------------------------------------------
+extern "C" int cp_head(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels, int64_t n_groups,
+                       int32_t V, int32_t want_grad, void* ws, size_t ws_bytes, float* loss_correct, int32_t* pred,
+                       float* logits, cp_params* grads, void* stream) {
+    WS w;
+    if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
+    if (!p || !z || !labels || !loss_correct || !pred || V <= 0 || n_groups * CP_TASKS != cfg->n_windows)
+        return fail(CP_ERR_ARG, "cp_head args");
+    if (want_grad && (!grads || !grads->easy_w || !grads->easy_b)) return fail(CP_ERR_ARG, "cp_head grads");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = (unsigned char*)ws;
+    const size_t es = cfg->dtype == CP_BF16 ? 2 : 4;
+    if (want_grad) CK(hipMemsetAsync(base + w.dz, 0, (size_t)cfg->n_windows * 64 * es, st));
+    HeadArgs a{};
+    a.z = z; a.easy_w = p->easy_w; a.easy_b = p->easy_b; a.labels = labels;
+    a.G = n_groups; a.V = V; a.want_grad = want_grad; a.dz_ld = 64; a.dz = base + w.dz;
+    a.logits = logits; a.pred = pred; a.partials = (float*)(base + w.head_part);
+    const int blocks = grid_rows(n_groups, HEAD_WAVES, kHeadBlocksMax);
+    if (cfg->dtype == CP_BF16)
+        hipLaunchKernelGGL((head_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((head_kernel<float>), dim3(blocks), dim3(256), 0, st, a);
+    CKL("head_kernel");
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, a.partials, blocks, n_groups, p->easy_w, p->easy_b,
+                       want_grad, loss_correct, want_grad ? grads->easy_w : nullptr, want_grad ? grads->easy_b : nullptr);
+    CKL("head_finalize_kernel");
+    return 0;
+}
+
+extern "C" int cp_vote(const int32_t* pred, const int64_t* labels, int64_t B, int32_t V, float* curve, int32_t* y_pred,
+                       void* stream) {
+    if (!pred || !labels || !curve || !y_pred || B <= 0 || V <= 0 || V > 32) return fail(CP_ERR_ARG, "cp_vote args");
+    hipLaunchKernelGGL(vote_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, pred, labels, B, (int)V, curve, y_pred);
+    CKL("vote_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// encoder backward
+// ---------------------------------------------------------------------------------------
+static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t* rows_per_split) {
+    int64_t rps = (M + target_splits - 1) / target_splits;
+    rps = ((rps + 31) / 32) * 32;
+    if (rps < 32) rps = 32;
+    *rows_per_split = rps;
+    *splits = (int)((M + rps - 1) / rps);
+}
+
+template <typename T>
+static int encoder_backward_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
+                              cp_params* g, hipStream_t st) {
+    using D = DT<T>;
+    const int64_t N = c->n_windows, R12 = N * 12;
+    const bool drop = c->training && c->dp_emg > 0.f;
+    float* partials = (float*)(base + w.partials);
+    float* slabs = (float*)(base + w.slabs);
+    float* coef = (float*)(base + w.coef);
+    auto act = [&](int l) { return (T*)(base + w.act[l]); };
+    auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
+    const int tiles_n = (int)((N + 127) / 128);
+
+    for (int i = 0; i < CP_N_FC; ++i) {
+        const int K = fcK(i);
+        hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(256), dim3(256), 0, st, p->fc_w[i], (T*)(base + w.wfc_t[i]), 512, K, 512,
+                           i == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(64), dim3(256), 0, st, p->last_w, (T*)(base + w.wlast_t), CP_D_E, 512, 64, 0);
+    CKL("transpose_w_kernel");
+
+    T* dz = (T*)(base + w.dz);
+    T* cur = (T*)(base + w.gbuf[0]);
+    T* nxt = (T*)(base + w.gbuf[1]);
+    // ---- projection ------------------------------------------------------------------
+    {
+        const T* Y = drop ? (const T*)(base + w.u[3]) : act(8);
+        const float *s = nullptr, *t = nullptr;
+        float* dzsum = (float*)(base + w.dzsum);
+        if (!drop) {
+            s = stats(8) + 2 * 512; t = stats(8) + 3 * 512;
+            const int gb = grid_rows(N, 256 / (CP_D_E / D::EPC), 512);
+            hipLaunchKernelGGL((colsum_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, dz, partials, N, 64, CP_D_E);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, partials, gb, CP_D_E, dzsum);
+            CKL("colsum(dz)");
+        }
+        GemmTNArgs ta{};
+        ta.X = dz; ta.ldx = 64; ta.Y = Y; ta.ldy = 512; ta.slabs = slabs; ta.M = N; ta.P = 64; ta.Q = 512;
+        int S;
+        split_rows(N, 128, &S, &ta.rows_per_split);
+        CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0);
+        CKL("reduce_slabs(last)");
+        GemmNTArgs a{};
+        a.A = dz; a.lda = 64; a.M = N; a.K = 64;
+        a.W = base + w.wlast_t; a.F = 512;
+        a.C = cur; a.ldc = 512; a.R = act(8); a.ldr = 512; a.partials = partials;
+        if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
+        CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_DGRAD>(a, st)));
+    }
+    // ---- fc7 .. fc1 --------------------------------------------------------------------
+    for (int L = 8; L >= 2; --L) {
+        const int i = L - 2, Lp = L - 1, K = fcK(i);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(256), 0, st, partials, tiles_n, (double)N, stats(L), coef,
+                           g->bn_g[L], g->bn_b[L], 512, 1);
+        CKL("bn_bwd_finalize_kernel");
+        const int gb = grid_rows(N, 256 / (512 / D::EPC), 1024);
+        hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(2), dim3(256), 0, st, partials, gb, 512, g->fc_b[i]);
+        CKL("bn_relu_bwd_kernel");
+        const bool in_drop = drop && Lp >= 5;
+        const T* Y = in_drop ? (const T*)(base + w.u[Lp - 5]) : act(Lp);
+        const float* s = in_drop ? nullptr : stats(Lp) + 2 * kLayerC[Lp];
+        const float* t = in_drop ? nullptr : stats(Lp) + 3 * kLayerC[Lp];
+        GemmTNArgs ta{};
+        ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
+        int S;
+        split_rows(N, 32, &S, &ta.rows_per_split);
+        CK((launch_gemm_tn<T, 128, 128, YLOAD_PLAIN>(ta, S, st)));
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
+                           i == 0 ? 1 : 0);
+        CKL("reduce_slabs(fc)");
+        GemmNTArgs a{};
+        a.A = cur; a.lda = 512; a.M = N; a.K = 512;
+        a.W = base + w.wfc_t[i]; a.F = K;
+        a.C = nxt; a.ldc = K; a.R = act(Lp); a.ldr = K; a.partials = partials;
+        if (in_drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
+        CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_DGRAD>(a, st)));
+        T* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
+    {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, tiles_n, (double)R12, stats(1), coef,
+                           g->bn_g[1], g->bn_b[1], 64, 12);
+        CKL("bn_bwd_finalize_kernel(conv2)");
+        const int gb = grid_rows(R12, 256 / (64 / D::EPC), 1024);
+        hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, partials, gb, 64, g->conv2_b);
+        CKL("bn_relu_bwd_kernel(conv2)");
+        GemmTNArgs ta{};
+        ta.X = cur; ta.ldx = 64; ta.Y = act(0); ta.ldy = 64; ta.slabs = slabs; ta.M = R12; ta.P = 64; ta.Q = 192;
+        ta.y_scale = stats(0) + 2 * 64; ta.y_shift = stats(0) + 3 * 64;
+        int S;
+        split_rows(R12, 256, &S, &ta.rows_per_split);
+        CK((launch_gemm_tn<T, 64, 64, YLOAD_CONV>(ta, S, st)));
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, slabs, S, 64, 192, 64, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2);
+        CKL("reduce_slabs(conv2)");
+        GemmNTArgs a{};
+        a.A = cur; a.lda = 64; a.M = R12; a.K = 192;
+        a.W = base + w.wc2_d; a.F = 64;
+        a.C = nxt; a.ldc = 64; a.R = act(0); a.ldr = 64; a.partials = partials;
+        CK((launch_gemm_nt<T, 128, 64, ALOAD_CONV, EPI_DGRAD>(a, st)));
+    }
+    // ---- conv1 -----------------------------------------------------------------------------
+    {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int)((R12 + 127) / 128), (double)R12,
+                           stats(0), coef, g->bn_g[0], g->bn_b[0], 64, 1);
+        CKL("bn_bwd_finalize_kernel(conv1)");
+        constexpr int RPP = 256 / (64 / D::EPC);
+        const int gb = grid_rows(R12, RPP, 1024);
+        hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, act(0), x, coef, partials, R12);
+        hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, gb, g->conv1_w, g->conv1_b);
+        CKL("conv1_bwd_kernel");
+    }
+    return 0;
+}
+
+extern "C" int cp_encoder_backward(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,
+                                   cp_params* grads, void* stream) {
+    WS w;
+    if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
+    if (!p || !x || !grads) return fail(CP_ERR_ARG, "cp_encoder_backward args");
+    if (cfg->dtype == CP_BF16)
+        return encoder_backward_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream);
+    return encoder_backward_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// optimiser
+// ---------------------------------------------------------------------------------------
+static int build_opt(OptArgs* a, const int64_t* off, const int64_t* numel, const int32_t* group, const int32_t* l2, int n) {
+    if (n <= 0 || n > CP_MAX_TENSORS || !off || !numel || !group || !l2) return fail(CP_ERR_ARG, "tensor table");
+    int chunk = 0;
+    for (int i = 0; i < n; ++i) {
+        a->t[i].offset = off[i];
+        a->t[i].numel = numel[i];
+        a->t[i].chunk0 = chunk;
+        a->t[i].nchunks = (int)((numel[i] + OPT_CHUNK - 1) / OPT_CHUNK);
+        a->t[i].group = group[i] ? 1 : 0;
+        a->t[i].l2 = l2[i] ? 1 : 0;
+        chunk += a->t[i].nchunks;
+    }
+    a->n_tensors = n;
+    a->total_chunks = chunk;
+    return 0;
+}
+
+extern "C" size_t cp_optimizer_scratch_floats(const int64_t* numel_host, int32_t n) {
+    size_t chunks = 0;
+    for (int i = 0; i < n; ++i) chunks += (size_t)((numel_host[i] + OPT_CHUNK - 1) / OPT_CHUNK);
+    return chunks + CP_MAX_TENSORS + 64;
+}
+
+static int launch_norms(OptArgs& a, float* scratch, float* l2_out, hipStream_t st) {
+    a.norm_partials = scratch;
+    a.norms = scratch + a.total_chunks;
+    a.l2_out = l2_out;
+    hipLaunchKernelGGL(l2_sumsq_kernel, dim3(a.total_chunks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(l2_finalize_kernel, dim3(1), dim3(CP_MAX_TENSORS), 0, st, a);
+    CKL("l2 norms");
+    return 0;
+}
+
+extern "C" int cp_l2_norms(const float* params_flat, const int64_t* offset_host, const int64_t* numel_host,
+                           const int32_t* group_host, const int32_t* l2_host, int32_t n, const cp_adam_hyper* h,
+                           float* scratch, float* l2_out, void* stream) {
+    if (!params_flat || !h || !scratch || !l2_out) return fail(CP_ERR_ARG, "cp_l2_norms args");
+    OptArgs a{};
+    if (int e = build_opt(&a, offset_host, numel_host, group_host, l2_host, n)) return e;
+    a.p = const_cast<float*>(params_flat);
+    a.reg[0] = h->reg_emg; a.reg[1] = h->reg_glove;
+    return launch_norms(a, scratch, l2_out, (hipStream_t)stream);
+}
+
+extern "C" int cp_l2_adam_step(float* params_flat, const float* grads_flat, float* exp_avg, float* exp_avg_sq,
+                               const int64_t* offset_host, const int64_t* numel_host, const int32_t* group_host,
+                               const int32_t* l2_host, int32_t n, const cp_adam_hyper* h, int64_t step_index, float* scratch,
+                               float* l2_out, void* stream) {
+    if (!params_flat || !grads_flat || !exp_avg || !exp_avg_sq || !h || !scratch || !l2_out || step_index < 1)
+        return fail(CP_ERR_ARG, "cp_l2_adam_step args");
+    OptArgs a{};
+    if (int e = build_opt(&a, offset_host, numel_host, group_host, l2_host, n)) return e;
+    a.p = params_flat; a.g = grads_flat; a.m = exp_avg; a.v = exp_avg_sq;
+    a.lr[0] = h->lr_emg; a.lr[1] = h->lr_glove; a.reg[0] = h->reg_emg; a.reg[1] = h->reg_glove;
+    a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.grad_scale = h->grad_scale;
+    a.bc1 = (float)(1.0 - pow((double)h->beta1, (double)step_index));
+    a.bc2 = (float)(1.0 - pow((double)h->beta2, (double)step_index));
+    if (int e = launch_norms(a, scratch, l2_out, (hipStream_t)stream)) return e;
+    hipLaunchKernelGGL(adam_kernel, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);
+    CKL("adam_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// debug access
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = DT<T>::load(in + i);
+}
+
+extern "C" int cp_debug_activation(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer, float* out, void* stream) {
+    WS w;
+    if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
+    if (layer < 0 || layer >= CP_N_BN + 4 || !out) return fail(CP_ERR_ARG, "cp_debug_activation args");
+    if (layer >= CP_N_BN && !(cfg->dp_emg > 0.f)) return fail(CP_ERR_ARG, "dropout buffers exist only when dp_emg > 0");
+    const int64_t n = cfg->n_windows * (layer < 2 ? 768 : 512);
+    unsigned char* base = (unsigned char*)ws;
+    const size_t off = layer < CP_N_BN ? w.act[layer] : w.u[layer - CP_N_BN];
+    if (cfg->dtype == CP_BF16)
+        hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(1024), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)(base + off), out, n);
+    else
+        hipLaunchKernelGGL((to_f32_kernel<float>), dim3(1024), dim3(256), 0, (hipStream_t)stream, (const float*)(base + off), out, n);
+    CKL("to_f32_kernel");
+    return 0;
+}
+
+extern "C" int cp_debug_bn_stats(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer, float* out, void* stream) {
+    WS w;
+    if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
+    if (layer < 0 || layer >= CP_N_BN || !out) return fail(CP_ERR_ARG, "cp_debug_bn_stats args");
+    CK(hipMemcpyAsync(out, (unsigned char*)ws + w.stats[layer], (size_t)4 * kLayerC[layer] * 4, hipMemcpyDeviceToDevice,
+                      (hipStream_t)stream));
+    return 0;
+}

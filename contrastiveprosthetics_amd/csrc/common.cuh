@@ -1,0 +1,112 @@
+// Shared device helpers for the gfx950 (CDNA4, MI355X) kernels of the contrastive
+// sEMG step.  wave = 64 lanes; MFMA tiles are 32x32; LDS tiles are 128-byte rows
+// of eight 16-byte chunks.  No portability layer: this is gfx950-only code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                            // bf16 storage
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CP_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {                   // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- per-dtype traits: a "chunk" is 16 bytes -----------------------------------
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int EPC = 4;                                   // elements per chunk
+    static constexpr int BK = 32;                                   // k per 128-byte LDS row
+    static constexpr int KSTEP = 8;                                 // k consumed per (h=0,1) chunk pair
+    __device__ static __forceinline__ void unpack(const uint4& c, float* o) {
+        o[0] = __uint_as_float(c.x); o[1] = __uint_as_float(c.y);
+        o[2] = __uint_as_float(c.z); o[3] = __uint_as_float(c.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* v) {
+        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
+    __device__ static __forceinline__ float round(float v) { return v; }
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int EPC = 8;
+    static constexpr int BK = 64;
+    static constexpr int KSTEP = 16;
+    __device__ static __forceinline__ void unpack(const uint4& c, float* o) {
+        o[0] = __uint_as_float(c.x << 16); o[1] = __uint_as_float(c.x & 0xFFFF0000u);
+        o[2] = __uint_as_float(c.y << 16); o[3] = __uint_as_float(c.y & 0xFFFF0000u);
+        o[4] = __uint_as_float(c.z << 16); o[5] = __uint_as_float(c.z & 0xFFFF0000u);
+        o[6] = __uint_as_float(c.w << 16); o[7] = __uint_as_float(c.w & 0xFFFF0000u);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* v) {
+        return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    }
+    __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// ---- MFMA on one 16-byte chunk pair ---------------------------------------------
+// a: chunk of the MFMA "A" operand row (lane&31), k-range selected by lane>>5
+// b: chunk of the MFMA "B" operand column (lane&31), same k-range.
+// bf16: one v_mfma_f32_32x32x16_bf16 (k = 8h..8h+7).  f32: four
+// v_mfma_f32_32x32x2_f32, element e pairs k = 4h+e of both operands (exact f32 fma chain).
+template <typename T> __device__ __forceinline__ void mma_chunk(const uint4& a, const uint4& b, f32x16& acc);
+template <> __device__ __forceinline__ void mma_chunk<bf16_t>(const uint4& a, const uint4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_chunk<float>(const uint4& a, const uint4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+// accumulator register g of a 32x32 tile holds D[row = (g&3) + 8*(g>>2) + 4*(lane>>5)][col = lane&31]
+
+// ---- 128-byte-row LDS tile, XOR-swizzled so 16 rows x one chunk column hit 16 slots ----
+__device__ __forceinline__ int lds_tile_off(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// ---- counter-based dropout mask (two 16-bit draws per hash) -----------------------
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// element (row, col) of an [rows x ld] tensor; ld even, col even -> draws for col, col+1
+__device__ __forceinline__ uint32_t dropout_pair(uint32_t key, uint32_t row, uint32_t ld, uint32_t col) {
+    return hash32(((row * ld + col) >> 1) * 0x9E3779B1U + key);
+}
+__device__ __forceinline__ float dropout_scale(uint32_t pair, int odd, uint32_t thresh, float inv_keep) {
+    uint32_t d = odd ? (pair >> 16) : (pair & 0xFFFFu);
+    return d >= thresh ? inv_keep : 0.0f;
+}
+
+// ---- reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

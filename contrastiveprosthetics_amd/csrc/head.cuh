@@ -1,0 +1,269 @@
+// Contrastive head: one wavefront per group of 41 windows.
+//   z_hat = z/|z|, E_hat = E/|E| with E[c] = W_easy[:,c] + b_easy            (code/models.py:123-125, 457-458)
+//   logits[g][i][j] = z_hat[g,i] . E_hat[label(g,j)]                          (code/models.py:127-129)
+//   loss = 1/(2*G*41) * sum_g sum_i [ -log softmax_j(l[i,:])[y_i] - log softmax_i(l[:,i'])[y_i'] ]
+//                                                                             (code/models.py:146-147, 204-207)
+//   pred[g][i] = argmax_j l[i][j]                                             (code/models.py:149)
+// and, when grads are requested, d loss / d z (through the normalisation) and d loss / d E_hat.
+// 41 <= 64 lanes: lane i owns row i (and column i in the column pass); the 41x41 tile moves
+// between the two views through a per-wave LDS tile with an odd pitch (conflict-free both ways);
+// row/column softmax reductions are register loops per lane, group reductions are wave shuffles.
+#pragma once
+#include "common.cuh"
+
+#define HEAD_T 41
+#define HEAD_D 16
+#define HEAD_WAVES 4
+
+struct HeadArgs {
+    const float* z;          // [N][16] encoder output, window order (b, t, v)
+    const float* easy_w;     // (16,41)
+    const float* easy_b;     // (16)
+    const int64_t* labels;   // [B*41]
+    int64_t G;               // groups = B*V
+    int V;
+    int want_grad;
+    int dz_ld;               // row pitch of dz (elements)
+    void* dz;                // [N][dz_ld] T (cols 0..15 written)
+    float* logits;           // optional [G][41][41]
+    int32_t* pred;           // [G][41]
+    float* partials;         // [blocks][HEAD_PART] : loss sum, correct count, dE_hat[41][16]
+};
+#define HEAD_PART (2 + HEAD_T * HEAD_D)
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+    using D = DT<T>;
+    __shared__ float Eh[HEAD_T][HEAD_D];                 // normalised class table
+    __shared__ float Ls[HEAD_WAVES][HEAD_T][HEAD_T + 2]; // logits / dlogits tile per wave (odd pitch 43)
+    __shared__ float Zs[HEAD_WAVES][HEAD_T][HEAD_D];     // z_hat rows per wave
+    __shared__ float Cl[HEAD_WAVES][HEAD_T + 3];         // column log-sum-exp per wave
+    __shared__ int Cls[HEAD_WAVES][HEAD_T + 3];          // class of position j in this group
+    __shared__ float dE[HEAD_WAVES][HEAD_T][HEAD_D];     // per-wave accumulator of d/dE_hat (by class)
+    __shared__ float wl[HEAD_WAVES], wc[HEAD_WAVES];
+    __shared__ int Tg[HEAD_T + 3];                       // CE target column of row i = labels[i]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < HEAD_T; i += 256) {
+        float e[HEAD_D], n = 0.f;
+#pragma unroll
+        for (int d = 0; d < HEAD_D; ++d) { e[d] = a.easy_w[d * HEAD_T + i] + a.easy_b[d]; n = fmaf(e[d], e[d], n); }
+        n = sqrtf(n);
+#pragma unroll
+        for (int d = 0; d < HEAD_D; ++d) Eh[i][d] = e[d] / n;
+        Tg[i] = (int)a.labels[i];
+    }
+    for (int i = tid; i < HEAD_WAVES * HEAD_T * HEAD_D; i += 256) (&dE[0][0][0])[i] = 0.f;
+    __syncthreads();
+
+    const bool act = lane < HEAD_T;
+    const int li = act ? lane : 0;
+    const int tgt = Tg[li];
+    const float cscale = 1.0f / (2.0f * (float)a.G * (float)HEAD_T);
+    float loss_acc = 0.f, corr_acc = 0.f;
+
+    for (int64_t g = (int64_t)blockIdx.x * HEAD_WAVES + wave; g < a.G; g += (int64_t)gridDim.x * HEAD_WAVES) {
+        const int64_t b = g / a.V;
+        const int v = (int)(g % a.V);
+        const int64_t zrow = (b * HEAD_T + li) * a.V + v;
+        if (act) Cls[wave][lane] = (int)a.labels[b * HEAD_T + lane];
+        float zh[HEAD_D], nz = 0.f;
+        {
+            const float4* zp = (const float4*)(a.z + zrow * HEAD_D);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t4 = zp[q];
+                zh[4 * q] = t4.x; zh[4 * q + 1] = t4.y; zh[4 * q + 2] = t4.z; zh[4 * q + 3] = t4.w;
+            }
+#pragma unroll
+            for (int d = 0; d < HEAD_D; ++d) nz = fmaf(zh[d], zh[d], nz);
+            nz = sqrtf(nz);
+#pragma unroll
+            for (int d = 0; d < HEAD_D; ++d) zh[d] = zh[d] / nz;
+        }
+        if (act) {
+#pragma unroll
+            for (int d = 0; d < HEAD_D; ++d) Zs[wave][lane][d] = zh[d];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- row pass: lane i owns logits[i][:] --------------------------------------
+        float l[HEAD_T];
+        float mx = -INFINITY, lt = 0.f;
+        int arg = 0;
+#pragma unroll
+        for (int j = 0; j < HEAD_T; ++j) {
+            const float* e = Eh[Cls[wave][j]];
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HEAD_D; ++d) s = fmaf(zh[d], e[d], s);
+            l[j] = s;
+            if (s > mx) { mx = s; arg = j; }
+            if (j == tgt) lt = s;
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < HEAD_T; ++j) se += __expf(l[j] - mx);
+        const float lse = mx + __logf(se);
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < HEAD_T; ++j) Ls[wave][lane][j] = l[j];
+            loss_acc += lse - lt;
+            corr_acc += (arg == tgt) ? 1.f : 0.f;
+            a.pred[g * HEAD_T + lane] = arg;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (a.logits != nullptr) {
+            float* lo = a.logits + g * (HEAD_T * HEAD_T);
+            for (int i = lane; i < HEAD_T * HEAD_T; i += 64) lo[i] = Ls[wave][i / HEAD_T][i % HEAD_T];
+        }
+        // ---- column pass: lane j owns logits[:][j] -----------------------------------
+        {
+            float cm = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < HEAD_T; ++i) cm = fmaxf(cm, Ls[wave][i][li]);
+            float cs = 0.f;
+#pragma unroll
+            for (int i = 0; i < HEAD_T; ++i) cs += __expf(Ls[wave][i][li] - cm);
+            const float clse = cm + __logf(cs);
+            if (act) {
+                Cl[wave][lane] = clse;
+                loss_acc += clse - Ls[wave][tgt][lane];      // column j's target row is labels[j]
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (a.want_grad) {
+            // dl[i][j] = c * (P_row + P_col - [j == y_i] - [i == y_j])
+            float dzh[HEAD_D];
+#pragma unroll
+            for (int d = 0; d < HEAD_D; ++d) dzh[d] = 0.f;
+            const float inv_se = 1.0f / se;
+#pragma unroll
+            for (int j = 0; j < HEAD_T; ++j) {
+                float dl = __expf(l[j] - mx) * inv_se + __expf(l[j] - Cl[wave][j]);
+                dl -= (j == tgt) ? 1.f : 0.f;
+                dl -= (Tg[j] == li) ? 1.f : 0.f;
+                dl *= cscale;
+                const float* e = Eh[Cls[wave][j]];
+#pragma unroll
+                for (int d = 0; d < HEAD_D; ++d) dzh[d] = fmaf(dl, e[d], dzh[d]);
+                l[j] = dl;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < HEAD_T; ++j) Ls[wave][lane][j] = l[j];
+                // through the normalisation: dz = (dzh - zh (zh.dzh)) / |z|
+                float dot = 0.f;
+#pragma unroll
+                for (int d = 0; d < HEAD_D; ++d) dot = fmaf(zh[d], dzh[d], dot);
+                float o[HEAD_D];
+#pragma unroll
+                for (int d = 0; d < HEAD_D; ++d) o[d] = (dzh[d] - zh[d] * dot) / nz;
+                T* dst = (T*)a.dz + zrow * a.dz_ld;
+#pragma unroll
+                for (int c = 0; c < HEAD_D / D::EPC; ++c) *(uint4*)(dst + c * D::EPC) = D::pack(o + c * D::EPC);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // d/dE_hat[class of j] += sum_i dl[i][j] * z_hat[i]      (lane j owns column j)
+            if (act) {
+                float accd[HEAD_D];
+#pragma unroll
+                for (int d = 0; d < HEAD_D; ++d) accd[d] = 0.f;
+#pragma unroll 4
+                for (int i = 0; i < HEAD_T; ++i) {
+                    const float dl = Ls[wave][i][lane];
+#pragma unroll
+                    for (int d = 0; d < HEAD_D; ++d) accd[d] = fmaf(dl, Zs[wave][i][d], accd[d]);
+                }
+                const int c = Cls[wave][lane];
+#pragma unroll
+                for (int d = 0; d < HEAD_D; ++d) atomicAdd(&dE[wave][c][d], accd[d]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    loss_acc = wave_sum(act ? loss_acc : 0.f);
+    corr_acc = wave_sum(act ? corr_acc : 0.f);
+    if (lane == 0) { wl[wave] = loss_acc; wc[wave] = corr_acc; }
+    __syncthreads();
+    float* part = a.partials + (int64_t)blockIdx.x * HEAD_PART;
+    if (tid == 0) {
+        part[0] = wl[0] + wl[1] + wl[2] + wl[3];
+        part[1] = wc[0] + wc[1] + wc[2] + wc[3];
+    }
+    for (int i = tid; i < HEAD_T * HEAD_D; i += 256) {
+        const float* p = &dE[0][0][0];
+        part[2 + i] = p[i] + p[HEAD_T * HEAD_D + i] + p[2 * HEAD_T * HEAD_D + i] + p[3 * HEAD_T * HEAD_D + i];
+    }
+}
+
+// one block: loss, correct count, class-table gradient (through E/|E| and E = W[:,c] + b)
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ partials, int nblocks, int64_t G,
+                                                            const float* __restrict__ easy_w, const float* __restrict__ easy_b,
+                                                            int want_grad, float* __restrict__ out /* loss, correct */,
+                                                            float* __restrict__ d_easy_w, float* __restrict__ d_easy_b) {
+    __shared__ double dEh[HEAD_T][HEAD_D];
+    __shared__ float dEc[HEAD_T][HEAD_D];
+    const int tid = threadIdx.x;
+    if (tid < 2) {
+        double s = 0;
+        for (int b = 0; b < nblocks; ++b) s += (double)partials[(int64_t)b * HEAD_PART + tid];
+        out[tid] = tid == 0 ? (float)(s / (2.0 * (double)G * HEAD_T)) : (float)s;
+    }
+    if (!want_grad) return;
+    for (int i = tid; i < HEAD_T * HEAD_D; i += 256) {
+        double s = 0;
+        for (int b = 0; b < nblocks; ++b) s += (double)partials[(int64_t)b * HEAD_PART + 2 + i];
+        (&dEh[0][0])[i] = s;
+    }
+    __syncthreads();
+    if (tid < HEAD_T) {
+        float e[HEAD_D], n = 0.f;
+        for (int d = 0; d < HEAD_D; ++d) { e[d] = easy_w[d * HEAD_T + tid] + easy_b[d]; n = fmaf(e[d], e[d], n); }
+        n = sqrtf(n);
+        float dot = 0.f;
+        for (int d = 0; d < HEAD_D; ++d) dot += (e[d] / n) * (float)dEh[tid][d];
+        for (int d = 0; d < HEAD_D; ++d) {
+            const float v = ((float)dEh[tid][d] - (e[d] / n) * dot) / n;
+            dEc[tid][d] = v;
+            d_easy_w[d * HEAD_T + tid] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < HEAD_D) {
+        float s = 0.f;
+        for (int c = 0; c < HEAD_T; ++c) s += dEc[c][tid];
+        d_easy_b[tid] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// eval majority vote (code/models.py:151-163): pred (B, V=25, 41) -> for every prefix length
+// win = 1..V the per-class mode over the first `win` samples; curve[b][win-1] = mean_t[mode == y_t].
+// torch.mode returns the smallest of the most frequent values.  One thread per (b, t).
+// ------------------------------------------------------------------------------------
+__global__ void vote_kernel(const int32_t* __restrict__ pred, const int64_t* __restrict__ labels, int64_t B, int V,
+                            float* __restrict__ curve /* [B][V] */, int32_t* __restrict__ y_pred /* [B][41] */) {
+    const int64_t b = blockIdx.x;
+    const int t = threadIdx.x;
+    __shared__ float hit[32][64];
+    unsigned char cnt[HEAD_T];
+    for (int c = 0; c < HEAD_T; ++c) cnt[c] = 0;
+    if (t < HEAD_T) {
+        const int y = (int)labels[t];
+        int best = 0, bestc = 0;
+        for (int w = 0; w < V; ++w) {
+            const int p = pred[(b * V + w) * HEAD_T + t];
+            const int c = ++cnt[p];
+            if (c > bestc || (c == bestc && p < best)) { best = p; bestc = c; }
+            hit[w][t] = (best == y) ? 1.f : 0.f;
+        }
+        y_pred[b * HEAD_T + t] = best;
+    }
+    __syncthreads();
+    if (t < V) {
+        float s = 0.f;
+        for (int i = 0; i < HEAD_T; ++i) s += hit[t][i];
+        curve[b * V + t] = s / HEAD_T;
+    }
+}

@@ -1,0 +1,437 @@
+// HBM-bound helper kernels of the encoder: conv1 (3-tap, VALU), BatchNorm statistics
+// finalisation, BN folding into the next layer's weights, dropout materialisation,
+// BN+ReLU backward, conv1 backward, weight-gradient slab reduction.
+// Activation layout inside the encoder: conv activations are stored position-major,
+// [window][w = 0..11][channel = 0..63]  (feature index k' = w*64 + c), so that a row
+// of the (window,position) x channel matrix is one contiguous 64-channel line.  The
+// reference's Flatten order k = c*12 + w (code/models.py:263) is restored where weights
+// of `emg_net.linear.0` are folded / their gradient is scattered.
+#pragma once
+#include "common.cuh"
+
+// ------------------------------------------------------------------------------------
+// gather: X[b][t][v][:] from the resident, mode-sliced table (code/utils.py:51-64,
+// code/load.py:256-273).  train: src row = emg_rand[t][perm[b]];  eval: 25 consecutive
+// rows of tensor[emg_rand[t][perm[b]]].  One thread per output float4 (3 per window).
+// ------------------------------------------------------------------------------------
+__global__ void gather_groups_kernel(const float* __restrict__ table, const int64_t* __restrict__ emg_rand,
+                                     const int64_t* __restrict__ perm, float* __restrict__ out, int64_t B, int T,
+                                     int V, int64_t D, int64_t table_rows) {
+    const int64_t total = B * T * V * 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % 3);
+        const int64_t win = i / 3;
+        const int v = (int)(win % V);
+        const int64_t bt = win / V;
+        const int t = (int)(bt % T);
+        const int64_t b = bt / T;
+        int64_t src = emg_rand[(int64_t)t * D + perm[b]] * V + v;      // row of the (rows,12) table
+        if (src < 0 || src >= table_rows) src = 0;
+        *(float4*)(out + win * 12 + q * 4) = *(const float4*)(table + src * 12 + q * 4);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// conv1 forward (code/models.py:255-257 restated for H=1: only kernel row 1 touches data)
+//   r1[m][c] = relu(b[c] + sum_tap W[c][tap] * x[window][w + tap - 1]),  m = window*12 + w
+// plus per-block per-channel sums of r1 and r1^2 for BatchNorm2d.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, T* __restrict__ out,
+                                                        float* __restrict__ partials, int64_t rows) {
+    using D = DT<T>;
+    constexpr int EPC = D::EPC, CPR = 64 / EPC, RPP = 256 / CPR;
+    __shared__ float red[2][RPP][64];
+    const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
+    float wt[EPC][3], bs[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = cc * EPC + e;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wt[e][k] = w[c * 9 + 3 + k];          // (64,1,3,3): row 1
+        bs[e] = bias[c];
+        s1[e] = s2[e] = 0.f;
+    }
+    for (int64_t m = (int64_t)blockIdx.x * RPP + rr; m < rows; m += (int64_t)gridDim.x * RPP) {
+        const int wpos = (int)(m % 12);
+        const float x0 = x[m];
+        const float xm = wpos > 0 ? x[m - 1] : 0.f;
+        const float xp = wpos < 11 ? x[m + 1] : 0.f;
+        float v[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float y = bs[e];
+            y = fmaf(wt[e][0], xm, y);
+            y = fmaf(wt[e][1], x0, y);
+            y = fmaf(wt[e][2], xp, y);
+            y = D::round(fmaxf(y, 0.f));
+            v[e] = y;
+            s1[e] += y;
+            s2[e] = fmaf(y, y, s2[e]);
+        }
+        *(uint4*)(out + m * 64 + cc * EPC) = D::pack(v);
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[0][rr][cc * EPC + e] = s1[e];
+        red[1][rr][cc * EPC + e] = s2[e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        float s = 0.f;
+        for (int q = 0; q < RPP; ++q) s += red[which][q][c];
+        partials[((int64_t)blockIdx.x * 2 + which) * 64 + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BatchNorm statistics -> affine (train: batch stats, biased variance, eps 1e-5; running
+// stats updated with momentum and the unbiased variance, as nn.BatchNorm does).
+// partials: [nrows][2][C] (sum, sum of squares).  use_running: eval with stock BN.
+// stats out: [4][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nrows, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, int update_running,
+                                                          int use_running, float momentum, float eps,
+                                                          float* __restrict__ stats, int C) {
+    __shared__ double red[2][4][64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s1 = 0, s2 = 0;
+    if (!use_running)
+        for (int r = g; r < nrows; r += 4) {
+            s1 += (double)partials[((int64_t)r * 2 + 0) * C + c];
+            s2 += (double)partials[((int64_t)r * 2 + 1) * C + c];
+        }
+    red[0][g][cl] = s1;
+    red[1][g][cl] = s2;
+    __syncthreads();
+    if (g == 0) {
+        float mean, var;
+        if (use_running) {
+            mean = running_mean[c];
+            var = running_var[c];
+        } else {
+            s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+            s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+            const double mu = s1 / count;
+            double vb = s2 / count - mu * mu;
+            if (vb < 0) vb = 0;
+            mean = (float)mu;
+            var = (float)vb;
+            if (update_running) {
+                const double unb = count > 1 ? vb * count / (count - 1) : vb;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+        const float invstd = 1.0f / sqrtf(var + eps);
+        const float sc = gamma[c] * invstd;
+        stats[0 * C + c] = mean;
+        stats[1 * C + c] = invstd;
+        stats[2 * C + c] = sc;
+        stats[3 * C + c] = beta[c] - mean * sc;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// fold the previous BN's affine into a Linear:  y = (r*s + t) W^T + b = r (W diag s)^T + (b + W t)
+//   mode 0: k' = k, channel = k               (512-wide inputs)
+//   mode 1: input is the conv stack: source k = c*12 + w, stored k' = w*64 + c, channel = c
+// out_w: [rows_out][K] T (rows >= F zero-filled, used to pad the 16-row projection to 32),
+// out_b: [F] f32 (nullable when the layer has no bias and no fold),  s/t nullable -> plain copy.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fold_linear_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                          const float* __restrict__ s, const float* __restrict__ t,
+                                                          T* __restrict__ out_w, float* __restrict__ out_b, int F, int K,
+                                                          int mode) {
+    using D = DT<T>;
+    __shared__ float red[4];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        int kp = k, ch = k;
+        if (mode == 1) { ch = k / 12; kp = (k % 12) * 64 + ch; }
+        float wv = 0.f;
+        if (j < F) {
+            wv = W[(int64_t)j * K + k];
+            if (s != nullptr) { acc = fmaf(wv, t[ch], acc); wv *= s[ch]; }
+        }
+        D::store(out_w + (int64_t)j * K + kp, wv);
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0 && out_b != nullptr && j < F) out_b[j] = (b ? b[j] : 0.f) + red[0] + red[1] + red[2] + red[3];
+}
+
+// transposed copy for the data-gradient GEMM:  out[k'][j] = W[j][k]   (ld_out >= F, zero padded)
+template <typename T>
+__global__ void transpose_w_kernel(const float* __restrict__ W, T* __restrict__ out, int F, int K, int ld_out, int mode) {
+    using D = DT<T>;
+    const int64_t total = (int64_t)K * ld_out;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % ld_out);
+        const int kp = (int)(i / ld_out);
+        int k = kp;
+        if (mode == 1) k = (kp & 63) * 12 + (kp >> 6);
+        D::store(out + i, j < F ? W[(int64_t)j * K + k] : 0.f);
+    }
+}
+
+// conv2 weights (64,64,3,3): kernel row 1 only.
+//   fwd[o][tap*64 + i]  = W[o][i][1][tap]
+//   dgr[i][tap*64 + o]  = W[o][i][1][2 - tap]     (flipped taps for the data gradient)
+template <typename T>
+__global__ void prep_conv2_kernel(const float* __restrict__ W, T* __restrict__ fwd, T* __restrict__ dgr) {
+    using D = DT<T>;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 64 * 192; idx += gridDim.x * blockDim.x) {
+        const int a = idx / 192, rem = idx % 192, tap = rem / 64, b = rem % 64;
+        D::store(fwd + idx, W[((a * 64 + b) * 3 + 1) * 3 + tap]);
+        D::store(dgr + idx, W[((b * 64 + a) * 3 + 1) * 3 + (2 - tap)]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// u = dropout(r*s + t)  (code/models.py:282,287,292,297: Dropout after BN of fc4..fc7)
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_dropout_apply_kernel(const T* __restrict__ r, const float* __restrict__ stats,
+                                                               T* __restrict__ u, int64_t rows, int C, uint32_t thresh,
+                                                               uint32_t key, float inv_keep) {
+    using D = DT<T>;
+    constexpr int EPC = D::EPC;
+    const int cpr = C / EPC;
+    const int64_t total = rows * cpr;
+    const float* s = stats + 2 * C;
+    const float* t = stats + 3 * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / cpr;
+        const int f = (int)(i % cpr) * EPC;
+        float v[EPC];
+        D::unpack(*(const uint4*)(r + m * C + f), v);
+#pragma unroll
+        for (int e = 0; e < EPC; e += 2) {
+            const uint32_t pr = dropout_pair(key, (uint32_t)m, (uint32_t)C, (uint32_t)(f + e));
+            v[e] = fmaf(v[e], s[f + e], t[f + e]) * dropout_scale(pr, 0, thresh, inv_keep);
+            v[e + 1] = fmaf(v[e + 1], s[f + e + 1], t[f + e + 1]) * dropout_scale(pr, 1, thresh, inv_keep);
+        }
+        *(uint4*)(u + m * C + f) = D::pack(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BN backward, step 1: reduce the data-gradient GEMM's per-block sums S1 = sum g, S2 = sum g*r
+// into the coefficients of   g_y = [r>0] * (ca*g + cb*r + cc)   and the gamma/beta gradients.
+//   x_hat = (r - mean)*invstd;  dgamma = sum g*x_hat;  dbeta = sum g
+//   g_r = s * (g - mean(g) - x_hat * mean(g*x_hat))
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nrows, double count,
+                                                              const float* __restrict__ stats, float* __restrict__ coef,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                                              int nfold) {
+    // nfold > 1: the partial rows are nfold*C wide (feature = w*C + channel, conv stack seen
+    // through the first Linear); the BatchNorm2d channel statistic sums over w.
+    __shared__ double red[2][4][64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int W = C * nfold;
+    double s1 = 0, s2 = 0;
+    for (int r = g; r < nrows; r += 4)
+        for (int f = 0; f < nfold; ++f) {
+            s1 += (double)partials[((int64_t)r * 2 + 0) * W + f * C + c];
+            s2 += (double)partials[((int64_t)r * 2 + 1) * W + f * C + c];
+        }
+    red[0][g][cl] = s1;
+    red[1][g][cl] = s2;
+    __syncthreads();
+    if (g == 0) {
+        s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        const double mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c];
+        const double dot = (s2 - mean * s1) * invstd;          // sum g * x_hat
+        const double c1 = s1 / count, c2 = dot / count;
+        coef[0 * C + c] = (float)sc;
+        coef[1 * C + c] = (float)(-sc * invstd * c2);
+        coef[2 * C + c] = (float)(-sc * (c1 - mean * invstd * c2));
+        dgamma[c] = (float)dot;
+        dbeta[c] = (float)s1;
+    }
+}
+
+// BN backward, step 2 + ReLU backward, in place; per-block column sums of g_y (bias gradient).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(T* __restrict__ g, const T* __restrict__ r,
+                                                          const float* __restrict__ coef, float* __restrict__ partials,
+                                                          int64_t rows, int C) {
+    using D = DT<T>;
+    constexpr int EPC = D::EPC;
+    extern __shared__ float dyn_red[];                  // [RPP][C]
+    const int cpr = C / EPC, rpp = 256 / cpr;
+    const int tid = threadIdx.x, cc = tid % cpr, rr = tid / cpr;
+    float ca[EPC], cb[EPC], cz[EPC], sum[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        ca[e] = coef[cc * EPC + e];
+        cb[e] = coef[C + cc * EPC + e];
+        cz[e] = coef[2 * C + cc * EPC + e];
+        sum[e] = 0.f;
+    }
+    for (int64_t m = (int64_t)blockIdx.x * rpp + rr; m < rows; m += (int64_t)gridDim.x * rpp) {
+        float gv[EPC], rv[EPC];
+        D::unpack(*(const uint4*)(g + m * C + cc * EPC), gv);
+        D::unpack(*(const uint4*)(r + m * C + cc * EPC), rv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float y = rv[e] > 0.f ? fmaf(ca[e], gv[e], fmaf(cb[e], rv[e], cz[e])) : 0.f;
+            y = D::round(y);
+            gv[e] = y;
+            sum[e] += y;
+        }
+        *(uint4*)(g + m * C + cc * EPC) = D::pack(gv);
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) dyn_red[rr * C + cc * EPC + e] = sum[e];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int q = 0; q < rpp; ++q) s += dyn_red[q * C + c];
+        partials[(int64_t)blockIdx.x * C + c] = s;
+    }
+}
+
+// column sums of an [rows][ld] T matrix (first C columns) -> partials[block][C]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ partials, int64_t rows,
+                                                     int ld, int C) {
+    using D = DT<T>;
+    constexpr int EPC = D::EPC;
+    extern __shared__ float dyn_red[];
+    const int cpr = C / EPC, rpp = 256 / cpr;
+    const int tid = threadIdx.x, cc = tid % cpr, rr = tid / cpr;
+    float sum[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) sum[e] = 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * rpp + rr; m < rows; m += (int64_t)gridDim.x * rpp) {
+        float v[EPC];
+        D::unpack(*(const uint4*)(x + m * ld + cc * EPC), v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sum[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) dyn_red[rr * C + cc * EPC + e] = sum[e];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int q = 0; q < rpp; ++q) s += dyn_red[q * C + c];
+        partials[(int64_t)blockIdx.x * C + c] = s;
+    }
+}
+
+// out[c] = sum_rows partials[row][c]  (f64 accumulation; one thread per column)
+__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nrows, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int r = 0; r < nrows; ++r) s += (double)partials[(int64_t)r * C + c];
+    out[c] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------
+// conv1 backward: the BN+ReLU backward of layer 1 fused with the weight/bias gradient
+// (conv1 needs no data gradient).  partials[block][4][64]: dW tap0..2, db.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const T* __restrict__ g, const T* __restrict__ r,
+                                                        const float* __restrict__ x, const float* __restrict__ coef,
+                                                        float* __restrict__ partials, int64_t rows) {
+    using D = DT<T>;
+    constexpr int EPC = D::EPC, CPR = 64 / EPC, RPP = 256 / CPR, C = 64;
+    __shared__ float red[4][RPP][64];
+    const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
+    float ca[EPC], cb[EPC], cz[EPC], acc[4][EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        ca[e] = coef[cc * EPC + e];
+        cb[e] = coef[C + cc * EPC + e];
+        cz[e] = coef[2 * C + cc * EPC + e];
+        acc[0][e] = acc[1][e] = acc[2][e] = acc[3][e] = 0.f;
+    }
+    for (int64_t m = (int64_t)blockIdx.x * RPP + rr; m < rows; m += (int64_t)gridDim.x * RPP) {
+        const int wpos = (int)(m % 12);
+        const float x0 = x[m];
+        const float xm = wpos > 0 ? x[m - 1] : 0.f;
+        const float xp = wpos < 11 ? x[m + 1] : 0.f;
+        float gv[EPC], rv[EPC];
+        D::unpack(*(const uint4*)(g + m * C + cc * EPC), gv);
+        D::unpack(*(const uint4*)(r + m * C + cc * EPC), rv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float y = rv[e] > 0.f ? fmaf(ca[e], gv[e], fmaf(cb[e], rv[e], cz[e])) : 0.f;
+            acc[0][e] = fmaf(y, xm, acc[0][e]);
+            acc[1][e] = fmaf(y, x0, acc[1][e]);
+            acc[2][e] = fmaf(y, xp, acc[2][e]);
+            acc[3][e] += y;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[k][rr][cc * EPC + e] = acc[k][e];
+    __syncthreads();
+    {
+        const int k = tid >> 6, c = tid & 63;
+        float s = 0.f;
+        for (int q = 0; q < RPP; ++q) s += red[k][q][c];
+        partials[((int64_t)blockIdx.x * 4 + k) * 64 + c] = s;
+    }
+}
+// dW1[c][0][1][tap] and db1[c] from the partials; the other kernel rows get zero data gradient.
+__global__ void conv1_bwd_finalize_kernel(const float* __restrict__ partials, int nrows, float* __restrict__ dW,
+                                          float* __restrict__ db) {
+    const int tid = threadIdx.x;                       // 256 threads: (k, c)
+    const int k = tid >> 6, c = tid & 63;
+    double s = 0;
+    for (int r = 0; r < nrows; ++r) s += (double)partials[((int64_t)r * 4 + k) * 64 + c];
+    if (k < 3) {
+        dW[c * 9 + 3 + k] = (float)s;
+        dW[c * 9 + 0 + k] = 0.f;
+        dW[c * 9 + 6 + k] = 0.f;
+    } else {
+        db[c] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// sum weight-gradient slabs, undo the BN fold and scatter into the reference's layout.
+//   mode 0 (fc):   grad[p*Q + q]      = s[q]*P + t[q]*dbsum[p]
+//   mode 1 (fc1):  q = w*64 + c  ->   grad[p*768 + c*12 + w] = s[c]*P + t[c]*dbsum[p]
+//   mode 2 (conv2): q = tap*64 + i -> grad[((p*64+i)*3+1)*3+tap] = P  (+ zero the dead kernel rows)
+//   rows p >= p_valid are dropped (projection padded 16 -> 64)
+// ------------------------------------------------------------------------------------
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int P, int Q, int p_valid,
+                                    const float* __restrict__ s, const float* __restrict__ t,
+                                    const float* __restrict__ dbsum, float* __restrict__ grad, int mode) {
+    const int64_t total = (int64_t)p_valid * Q;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / Q), q = (int)(i % Q);
+        float acc = 0.f;
+        for (int k = 0; k < S; ++k) acc += slabs[((int64_t)k * P + p) * Q + q];
+        if (mode == 2) {
+            const int tap = q >> 6, ii = q & 63;
+            const int base = (p * 64 + ii) * 9;
+            grad[base + 3 + tap] = acc;
+            grad[base + 0 + tap] = 0.f;
+            grad[base + 6 + tap] = 0.f;
+        } else {
+            int ch = q, dst = p * Q + q;
+            if (mode == 1) { ch = q & 63; dst = p * Q + ch * 12 + (q >> 6); }
+            if (s != nullptr) acc = fmaf(s[ch], acc, t[ch] * dbsum[p]);
+            grad[dst] = acc;
+        }
+    }
+}

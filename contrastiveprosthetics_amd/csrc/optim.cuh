@@ -1,0 +1,101 @@
+// L2 regulariser (sum of Frobenius norms, NOT squared -- code/models.py:344-349, 467-472) fused
+// with the two Adam optimisers of code/train.py:72-73,107-108, as three launches over one flat
+// parameter buffer: per-chunk sums of squares -> per-tensor norms -> Adam with the regulariser's
+// gradient reg * p / |p| added on the fly.
+#pragma once
+#include "common.cuh"
+
+#define CP_MAX_TENSORS 64
+#define OPT_CHUNK 2048
+
+struct OptTensor {
+    int64_t offset;   // into the flat buffers (floats)
+    int64_t numel;
+    int32_t chunk0;   // first chunk index of this tensor
+    int32_t nchunks;
+    int32_t group;    // 0 = emg_net, 1 = glove_net
+    int32_t l2;       // takes part in the regulariser
+};
+
+struct OptArgs {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    float* norm_partials;   // [total_chunks]
+    float* norms;           // [n_tensors]
+    float* l2_out;          // scalar: reg_glove * sum|q| + reg_emg * sum|p|
+    int n_tensors, total_chunks;
+    float lr[2], reg[2];
+    float beta1, beta2, eps, bc1, bc2, grad_scale;
+    OptTensor t[CP_MAX_TENSORS];
+};
+
+__device__ __forceinline__ int opt_find_tensor(const OptArgs& a, int chunk) {
+    int ti = 0;
+    for (int i = 0; i < a.n_tensors; ++i)
+        if (chunk >= a.t[i].chunk0) ti = i;
+    return ti;
+}
+
+__global__ __launch_bounds__(256) void l2_sumsq_kernel(OptArgs a) {
+    __shared__ float red[4];
+    const int chunk = blockIdx.x;
+    const int ti = opt_find_tensor(a, chunk);
+    const OptTensor& t = a.t[ti];
+    const int64_t base = (int64_t)(chunk - t.chunk0) * OPT_CHUNK;
+    float s = 0.f;
+    if (t.l2)
+        for (int i = threadIdx.x; i < OPT_CHUNK; i += 256) {
+            const int64_t e = base + i;
+            if (e < t.numel) { const float x = a.p[t.offset + e]; s = fmaf(x, x, s); }
+        }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.norm_partials[chunk] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void l2_finalize_kernel(OptArgs a) {
+    __shared__ double contrib[CP_MAX_TENSORS];
+    const int i = threadIdx.x;
+    double c = 0;
+    if (i < a.n_tensors) {
+        double s = 0;
+        for (int k = 0; k < a.t[i].nchunks; ++k) s += (double)a.norm_partials[a.t[i].chunk0 + k];
+        const float n = (float)sqrt(s);
+        a.norms[i] = n;
+        if (a.t[i].l2) c = (double)a.reg[a.t[i].group] * (double)n;
+    }
+    contrib[i] = c;
+    __syncthreads();
+    if (i == 0) {
+        double s = 0;
+        for (int k = 0; k < a.n_tensors; ++k) s += contrib[k];
+        *a.l2_out = (float)s;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(OptArgs a) {
+    const int chunk = blockIdx.x;
+    const int ti = opt_find_tensor(a, chunk);
+    const OptTensor& t = a.t[ti];
+    const int64_t base = (int64_t)(chunk - t.chunk0) * OPT_CHUNK;
+    const float lr = a.lr[t.group];
+    const float l2c = t.l2 ? a.reg[t.group] / a.norms[ti] : 0.f;
+    const float step = lr / a.bc1;
+    const float rs2 = 1.0f / sqrtf(a.bc2);
+    for (int i = threadIdx.x; i < OPT_CHUNK; i += 256) {
+        const int64_t e = base + i;
+        if (e >= t.numel) break;
+        const int64_t o = t.offset + e;
+        const float p = a.p[o];
+        float g = a.g[o] * a.grad_scale;
+        if (t.l2) g = fmaf(l2c, p, g);
+        const float m = a.beta1 * a.m[o] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[o] + (1.f - a.beta2) * g * g;
+        a.m[o] = m;
+        a.v[o] = v;
+        a.p[o] = p - step * (m / (sqrtf(v) * rs2 + a.eps));
+    }
+}

@@ -1,0 +1,291 @@
+"""Host-side driver of the HIP kernels: owns the flat parameter / gradient / Adam
+buffers and the workspace (as torch tensors -- PyTorch is only the allocator and
+the stream provider here) and issues the C-ABI calls of include/cpnative.h.
+
+Layout of the flat buffers: every trainable tensor of the reference ``Model``
+(code/models.py, state_dict order, ``logit_scale`` excluded because neither
+optimiser owns it, code/train.py:72-73), each aligned to 64 floats.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CP_BF16, CP_D_E, CP_F32, CP_N_BN, CP_N_FC, CP_TASKS
+
+LINEAR_IDX = (0, 3, 6, 9, 13, 17, 21)           # code/models.py:266-298
+LINEAR_BN_IDX = (2, 5, 8, 11, 15, 19, 23)
+
+
+def bn_bases(adabn: bool):
+    sfx = ".bn" if adabn else ""                # AdaBatchNorm wraps the BN as `.bn` (models.py:22,32)
+    return (["emg_net.conv_emg.2" + sfx, "emg_net.conv_emg.5" + sfx]
+            + [f"emg_net.linear.{i}{sfx}" for i in LINEAR_BN_IDX])
+
+
+def param_specs(adabn: bool, d_e: int = CP_D_E) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Trainable tensors in reference state_dict order, without logit_scale."""
+    bn = bn_bases(adabn)
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["emg_net.conv_emg.0.weight"] = (64, 1, 3, 3)
+    s["emg_net.conv_emg.0.bias"] = (64,)
+    s[bn[0] + ".weight"] = (64,)
+    s[bn[0] + ".bias"] = (64,)
+    s["emg_net.conv_emg.3.weight"] = (64, 64, 3, 3)
+    s["emg_net.conv_emg.3.bias"] = (64,)
+    s[bn[1] + ".weight"] = (64,)
+    s[bn[1] + ".bias"] = (64,)
+    k = 768
+    for n, li in enumerate(LINEAR_IDX):
+        s[f"emg_net.linear.{li}.weight"] = (512, k)
+        s[f"emg_net.linear.{li}.bias"] = (512,)
+        s[bn[2 + n] + ".weight"] = (512,)
+        s[bn[2 + n] + ".bias"] = (512,)
+        k = 512
+    s["emg_net.last.0.weight"] = (d_e, 512)
+    s["glove_net.easy.0.weight"] = (d_e, CP_TASKS)
+    s["glove_net.easy.0.bias"] = (d_e,)
+    s["glove_net.last.0.weight"] = (d_e, 256)
+    return s
+
+
+def l2_member(name: str) -> bool:
+    """code/models.py:344-349, 467-472: name (inside its sub-net) has neither 'bn' nor 'bias'."""
+    local = name.split(".", 1)[1]
+    return ("bn" not in local) and ("bias" not in local)
+
+
+class FlatStore:
+    """One contiguous f32 buffer with named views."""
+
+    def __init__(self, specs, device, fill: Optional[float] = 0.0):
+        self.offsets: "OrderedDict[str, Tuple[int, int]]" = OrderedDict()
+        off = 0
+        for k, shp in specs.items():
+            n = int(np.prod(shp))
+            self.offsets[k] = (off, n)
+            off += (n + 63) // 64 * 64
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        if fill:
+            self.flat.fill_(fill)
+        self.views: Dict[str, torch.Tensor] = {
+            k: self.flat[o:o + n].view(specs[k]) for k, (o, n) in self.offsets.items()}
+
+    def ptr(self, name: str) -> int:
+        return self.flat.data_ptr() + 4 * self.offsets[name][0]
+
+
+def _params_struct(store: FlatStore, adabn: bool) -> _lib.cp_params:
+    bn = bn_bases(adabn)
+    p = _lib.cp_params()
+    p.conv1_w = store.ptr("emg_net.conv_emg.0.weight")
+    p.conv1_b = store.ptr("emg_net.conv_emg.0.bias")
+    p.conv2_w = store.ptr("emg_net.conv_emg.3.weight")
+    p.conv2_b = store.ptr("emg_net.conv_emg.3.bias")
+    for n, li in enumerate(LINEAR_IDX):
+        p.fc_w[n] = store.ptr(f"emg_net.linear.{li}.weight")
+        p.fc_b[n] = store.ptr(f"emg_net.linear.{li}.bias")
+    for n, b in enumerate(bn):
+        p.bn_g[n] = store.ptr(b + ".weight")
+        p.bn_b[n] = store.ptr(b + ".bias")
+    p.last_w = store.ptr("emg_net.last.0.weight")
+    p.easy_w = store.ptr("glove_net.easy.0.weight")
+    p.easy_b = store.ptr("glove_net.easy.0.bias")
+    return p
+
+
+class Engine:
+    def __init__(self, adabn: bool = True, dtype: str = "bf16", dp_emg: float = 0.0, device="cuda",
+                 d_e: int = CP_D_E, seed: int = 0):
+        if d_e != CP_D_E:
+            raise ValueError(f"the HIP head kernel is built for d_e={CP_D_E} (code/train.py:183), got {d_e}")
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.CpNativeError("contrastiveprosthetics_amd runs on an MI355X (device 'cuda') only; no CPU path")
+        self.adabn = bool(adabn)
+        self.dtype = CP_BF16 if dtype == "bf16" else CP_F32
+        self.dp_emg = float(dp_emg)
+        self.seed = int(seed)
+        self.step_count = 0              # forward passes in train mode (dropout stream)
+        self.specs = param_specs(self.adabn, d_e)
+        self.values = FlatStore(self.specs, self.device)
+        self.grads = FlatStore(self.specs, self.device)
+        self.exp_avg = torch.zeros_like(self.values.flat)
+        self.exp_avg_sq = torch.zeros_like(self.values.flat)
+        self.adam_steps = 0
+        self.running: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        if not self.adabn:
+            for b in bn_bases(False):
+                n = self.specs[b + ".weight"][0]
+                self.running[b + ".running_mean"] = torch.zeros(n, device=self.device)
+                self.running[b + ".running_var"] = torch.ones(n, device=self.device)
+                self.running[b + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._p = _params_struct(self.values, self.adabn)
+        self._g = _params_struct(self.grads, self.adabn)
+        self._bn = _lib.cp_bn_buffers()
+        if not self.adabn:
+            for n, b in enumerate(bn_bases(False)):
+                self._bn.running_mean[n] = self.running[b + ".running_mean"].data_ptr()
+                self._bn.running_var[n] = self.running[b + ".running_var"].data_ptr()
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_windows = 0
+        names = list(self.specs)
+        self._tab_n = len(names)
+        self._tab_off = (C.c_int64 * self._tab_n)(*[self.values.offsets[k][0] for k in names])
+        self._tab_numel = (C.c_int64 * self._tab_n)(*[self.values.offsets[k][1] for k in names])
+        self._tab_group = (C.c_int32 * self._tab_n)(*[1 if k.startswith("glove_net.") else 0 for k in names])
+        self._tab_l2 = (C.c_int32 * self._tab_n)(*[1 if l2_member(k) else 0 for k in names])
+        nscratch = self.lib.cp_optimizer_scratch_floats(self._tab_numel, self._tab_n)
+        self._opt_scratch = torch.zeros(nscratch, device=self.device)
+        self._l2_out = torch.zeros(1, device=self.device)
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _cfg(self, n_windows: int, training: bool) -> _lib.cp_config:
+        c = _lib.cp_config()
+        c.n_windows = n_windows
+        c.dtype = self.dtype
+        c.adabn = 1 if self.adabn else 0
+        c.training = 1 if training else 0
+        c.dp_emg = self.dp_emg
+        c.bn_momentum = 0.1
+        c.bn_eps = 1e-5
+        c.seed = self.seed
+        c.step = self.step_count
+        return c
+
+    def workspace(self, n_windows: int) -> torch.Tensor:
+        if self._ws is None or n_windows > self._ws_windows:
+            nbytes = self.lib.cp_workspace_bytes(n_windows, self.dtype, self.dp_emg)
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_windows = n_windows
+        return self._ws
+
+    def _ws_args(self, n_windows):
+        # the carve depends on n_windows, so a call always passes the size for ITS n_windows
+        ws = self.workspace(n_windows)
+        return ws.data_ptr(), ws.numel()
+
+    # ------------------------------------------------------------------ stages
+    def gather(self, table: torch.Tensor, emg_rand: torch.Tensor, perm: torch.Tensor, V: int) -> torch.Tensor:
+        B = perm.numel()
+        out = torch.empty(B, CP_TASKS, V, 12, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.cp_gather_groups(table.data_ptr(), table.shape[0], emg_rand.data_ptr(), emg_rand.shape[1],
+                                             perm.data_ptr(), B, V, out.data_ptr(), self._stream()), "cp_gather_groups")
+        return out
+
+    def encoder_forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+        x = x.reshape(-1, 12)
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.device.type == "cuda"
+        n = x.shape[0]
+        if training:
+            self.step_count += 1
+        cfg = self._cfg(n, training)
+        z = torch.empty(n, CP_D_E, dtype=torch.float32, device=self.device)
+        ws, nb = self._ws_args(n)
+        bn = C.byref(self._bn) if not self.adabn else None
+        _lib.check(self.lib.cp_encoder_forward(C.byref(cfg), C.byref(self._p), bn, x.data_ptr(), ws, nb, z.data_ptr(),
+                                               self._stream()), "cp_encoder_forward")
+        if training and not self.adabn:
+            for b in bn_bases(False):
+                self.running[b + ".num_batches_tracked"] += 1
+        self._last = (n, training)
+        return z
+
+    def head(self, z: torch.Tensor, labels: torch.Tensor, V: int, want_grad: bool, want_logits: bool = False):
+        n = z.shape[0]
+        G = n // CP_TASKS
+        assert labels.dtype == torch.int64 and labels.numel() * V == n
+        cfg = self._cfg(n, self._last[1])
+        out = torch.empty(2, dtype=torch.float32, device=self.device)
+        pred = torch.empty(G, CP_TASKS, dtype=torch.int32, device=self.device)
+        logits = torch.empty(G, CP_TASKS, CP_TASKS, dtype=torch.float32, device=self.device) if want_logits else None
+        ws, nb = self._ws_args(n)
+        _lib.check(self.lib.cp_head(C.byref(cfg), C.byref(self._p), z.data_ptr(), labels.data_ptr(), G, V,
+                                    1 if want_grad else 0, ws, nb, out.data_ptr(), pred.data_ptr(),
+                                    logits.data_ptr() if want_logits else None, C.byref(self._g), self._stream()),
+                   "cp_head")
+        return out, pred, logits
+
+    def encoder_backward(self, x: torch.Tensor):
+        x = x.reshape(-1, 12)
+        n = x.shape[0]
+        cfg = self._cfg(n, True)
+        ws, nb = self._ws_args(n)
+        _lib.check(self.lib.cp_encoder_backward(C.byref(cfg), C.byref(self._p), x.data_ptr(), ws, nb, C.byref(self._g),
+                                                self._stream()), "cp_encoder_backward")
+
+    def vote(self, pred: torch.Tensor, labels: torch.Tensor, B: int, V: int):
+        curve = torch.empty(B, V, dtype=torch.float32, device=self.device)
+        y_pred = torch.empty(B, CP_TASKS, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.cp_vote(pred.data_ptr(), labels.data_ptr(), B, V, curve.data_ptr(), y_pred.data_ptr(),
+                                    self._stream()), "cp_vote")
+        return curve, y_pred
+
+    def _hyper(self, params: dict, grad_scale: float = 1.0, lr_scale=(1.0, 1.0)) -> _lib.cp_adam_hyper:
+        h = _lib.cp_adam_hyper()
+        h.lr_emg = float(params.get("lr_emg", 0.0)) * lr_scale[0]
+        h.lr_glove = float(params.get("lr_glove", 0.0)) * lr_scale[1]
+        h.reg_emg = float(params["reg_emg"])
+        h.reg_glove = float(params["reg_glove"])
+        h.beta1, h.beta2, h.eps = 0.9, 0.999, 1e-8
+        h.grad_scale = grad_scale
+        return h
+
+    def l2(self, params: dict) -> torch.Tensor:
+        h = self._hyper(params)
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.cp_l2_norms(self.values.flat.data_ptr(), self._tab_off, self._tab_numel, self._tab_group,
+                                        self._tab_l2, self._tab_n, C.byref(h), self._opt_scratch.data_ptr(),
+                                        out.data_ptr(), self._stream()), "cp_l2_norms")
+        return out
+
+    def adam_step(self, params: dict, grad_scale: float = 1.0, lr_scale=(1.0, 1.0)) -> torch.Tensor:
+        self.adam_steps += 1
+        h = self._hyper(params, grad_scale, lr_scale)
+        _lib.check(self.lib.cp_l2_adam_step(self.values.flat.data_ptr(), self.grads.flat.data_ptr(),
+                                            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self._tab_off,
+                                            self._tab_numel, self._tab_group, self._tab_l2, self._tab_n, C.byref(h),
+                                            self.adam_steps, self._opt_scratch.data_ptr(), self._l2_out.data_ptr(),
+                                            self._stream()), "cp_l2_adam_step")
+        return self._l2_out
+
+    # ------------------------------------------------------------------ debug (tests)
+    def debug_activation(self, layer: int) -> torch.Tensor:
+        n, training = self._last
+        C_ = 768 if layer < 2 else 512
+        out = torch.empty(n, C_, dtype=torch.float32, device=self.device)
+        cfg = self._cfg(n, training)
+        ws, nb = self._ws_args(n)
+        _lib.check(self.lib.cp_debug_activation(C.byref(cfg), ws, nb, layer, out.data_ptr(), self._stream()),
+                   "cp_debug_activation")
+        return out
+
+    def debug_bn_stats(self, layer: int) -> torch.Tensor:
+        n, training = self._last
+        C_ = 64 if layer < 2 else 512
+        out = torch.empty(4, C_, dtype=torch.float32, device=self.device)
+        cfg = self._cfg(n, training)
+        ws, nb = self._ws_args(n)
+        _lib.check(self.lib.cp_debug_bn_stats(C.byref(cfg), ws, nb, layer, out.data_ptr(), self._stream()),
+                   "cp_debug_bn_stats")
+        return out
+
+    # ------------------------------------------------------------------ state
+    def load_named(self, sd: Dict[str, torch.Tensor]):
+        for k in self.specs:
+            self.values.views[k].copy_(sd[k].to(self.device, torch.float32))
+        for k in self.running:
+            if k in sd:
+                self.running[k].copy_(sd[k].to(self.device))

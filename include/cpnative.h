@@ -1,0 +1,152 @@
+/* cpnative -- C ABI of the MI355X-native contrastive sEMG training path.
+ *
+ * The reference (FibonacciDude/ContrastiveProsthetics) is pure Python/PyTorch and has no
+ * FFI layer; its de-facto operator boundary is the Python class surface of `Model`,
+ * `EMGNet`, `GLOVENet` (code/models.py), `TaskWrapper` (code/utils.py), `DB23`
+ * (code/load.py) and the step in `train_loop` (code/train.py:95-108).  Every entry point
+ * below names the reference call site it replaces.  The library is what a maintainer binds
+ * with ctypes from those classes; `contrastiveprosthetics_amd/` is
+ * exactly such a binding.
+ *
+ * Conventions: plain pointers + sizes, no torch types.  All pointers are DEVICE pointers
+ * unless the name ends in `_host`.  `stream` is a hipStream_t passed as void*.  Every call
+ * only enqueues work on `stream`: no allocation, no synchronisation, no host read-back.
+ * Return value: 0 on success, otherwise a hipError_t (or CP_ERR_* below); the message is
+ * available from cp_last_error().  The library is gfx950-only and has no CPU fallback.
+ *
+ * Activations inside the workspace are stored in `dtype` (f32 = parity path computed with
+ * v_mfma_f32_32x32x2_f32, bf16 = throughput path computed with v_mfma_f32_32x32x16_bf16 and
+ * f32 accumulation); parameters, gradients, statistics, z, logits and the loss are f32.
+ */
+#ifndef CPNATIVE_H
+#define CPNATIVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CP_VERSION 100            /* 0.1.0 */
+#define CP_F32 0
+#define CP_BF16 1
+#define CP_TASKS 41               /* code/constants.py:45-48 */
+#define CP_EMG_DIM 12             /* code/constants.py:97 */
+#define CP_D_E 16                 /* embedding width (code/train.py:183) */
+#define CP_N_BN 9                 /* 2 x BatchNorm2d(64) + 7 x BatchNorm1d(512) */
+#define CP_N_FC 7
+#define CP_ERR_ARG 10001
+#define CP_ERR_WORKSPACE 10002
+
+/* Pointers to the trainable tensors of `Model` (values) or to their gradients.
+ * Shapes and state_dict keys: SURVEY.md section 8b / code/models.py:248-315, 412-428. */
+typedef struct cp_params {
+    float* conv1_w;            /* emg_net.conv_emg.0.weight (64,1,3,3) */
+    float* conv1_b;            /* emg_net.conv_emg.0.bias   (64)       */
+    float* conv2_w;            /* emg_net.conv_emg.3.weight (64,64,3,3)*/
+    float* conv2_b;            /* emg_net.conv_emg.3.bias   (64)       */
+    float* fc_w[CP_N_FC];      /* emg_net.linear.{0,3,6,9,13,17,21}.weight (512,768 | 512,512) */
+    float* fc_b[CP_N_FC];      /* ...bias (512) */
+    float* bn_g[CP_N_BN];      /* BN gamma: conv_emg.{2,5}, linear.{2,5,8,11,15,19,23} */
+    float* bn_b[CP_N_BN];      /* BN beta */
+    float* last_w;             /* emg_net.last.0.weight (16,512), no bias */
+    float* easy_w;             /* glove_net.easy.0.weight (16,41) */
+    float* easy_b;             /* glove_net.easy.0.bias   (16)    */
+} cp_params;
+
+/* running statistics of the stock nn.BatchNorm (code/models.py:238-243); all NULL for AdaBN
+ * (code/models.py:17-35: momentum 0, track_running_stats False). */
+typedef struct cp_bn_buffers {
+    float* running_mean[CP_N_BN];
+    float* running_var[CP_N_BN];
+} cp_bn_buffers;
+
+typedef struct cp_config {
+    int64_t n_windows;   /* rows through the encoder = groups * 41 (train: B*41, eval: B*41*25) */
+    int32_t dtype;       /* CP_F32 | CP_BF16 */
+    int32_t adabn;       /* 1: batch statistics in train AND eval (AdaBN); 0: stock BN */
+    int32_t training;    /* 1: model.train()  (batch stats, dropout, running-stat update) */
+    int32_t reserved;
+    float dp_emg;        /* Dropout p after BN of fc4..fc7 (code/models.py:282-297) */
+    float bn_momentum;   /* 0.1 */
+    float bn_eps;        /* 1e-5 */
+    float reserved2;
+    uint64_t seed;       /* dropout stream = f(seed, step, layer, element) */
+    uint64_t step;
+} cp_config;
+
+int cp_version(void);
+const char* cp_last_error(void);
+
+/* bytes of scratch needed by the calls below for up to `max_windows` encoder rows */
+size_t cp_workspace_bytes(int64_t max_windows, int32_t dtype, float dp_emg);
+
+/* TaskWrapper.__getitem__ + DB23.__getitem__/slice_batch + default_collate
+ * (code/utils.py:51-64, code/load.py:256-273, code/train.py:86,95) in one launch.
+ * table: DB23.EMG_use (table_rows,12) f32 (eval: the same memory viewed as (rows/25,25,12));
+ * emg_rand: TaskWrapper.emg_rand (41,D) int64; perm: the B item indices of this batch;
+ * x_out: (B,41,V,12) f32 -- the collated EMG tensor in encoder row order. */
+int cp_gather_groups(const float* table, int64_t table_rows, const int64_t* emg_rand, int64_t D,
+                     const int64_t* perm, int64_t B, int32_t V, float* x_out, void* stream);
+
+/* EMGNet.forward (code/models.py:319-342): conv_emg -> linear -> last.
+ * x (n_windows,12) f32; z_out (n_windows,16) f32 in the same row order (the regroup of
+ * models.py:337-341 is a pure index map applied by cp_head).  Saves what backward needs in ws. */
+int cp_encoder_forward(const cp_config* cfg, const cp_params* p, const cp_bn_buffers* bn,
+                       const float* x, void* ws, size_t ws_bytes, float* z_out, void* stream);
+
+/* Model.forward's normalise + bmm with GLOVENet.forward's one-hot Linear
+ * (code/models.py:121-130, 457-465), Model.loss / contrastive_loopy_loss
+ * (code/models.py:132-173, 198-208) and their gradient, fused.
+ * labels (B*41) int64; n_groups = B*V; loss_correct[0] = loss, [1] = number of rows whose
+ * argmax equals its label; pred (n_groups,41) int32; logits optional (n_groups,41,41) f32.
+ * want_grad: also writes dL/dz into ws (consumed by cp_encoder_backward) and the class-encoder
+ * gradients grads->easy_w / easy_b. */
+int cp_head(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels,
+            int64_t n_groups, int32_t V, int32_t want_grad, void* ws, size_t ws_bytes,
+            float* loss_correct, int32_t* pred, float* logits, cp_params* grads, void* stream);
+
+/* autograd of EMGNet (what loss.backward() does at code/train.py:105 for emg_net):
+ * consumes dL/dz left in ws by cp_head, writes every emg_net gradient into `grads`. */
+int cp_encoder_backward(const cp_config* cfg, const cp_params* p, const float* x, void* ws,
+                        size_t ws_bytes, cp_params* grads, void* stream);
+
+/* eval majority vote (code/models.py:151-163): pred (B,V,41) -> curve (B,V) of prefix-mode
+ * accuracies, y_pred (B,41) = mode over all V samples. */
+int cp_vote(const int32_t* pred, const int64_t* labels, int64_t B, int32_t V, float* curve,
+            int32_t* y_pred, void* stream);
+
+/* Model.l2() (code/models.py:225-228, 344-349, 467-472) + optimizer_emg.step() +
+ * optimizer_glove.step() (code/train.py:72-73, 101, 107-108) over one flat parameter buffer.
+ * Tensor table (host arrays, n <= 64): offset/numel into the flat buffers, group (0 emg_net,
+ * 1 glove_net), l2 (1 if the tensor's name contains neither 'bn' nor 'bias').
+ * step_index: 1-based Adam step.  grad_scale multiplies the data gradient (1/world_size after an
+ * all-reduce sum).  l2_out: device scalar receiving the regulariser value.  scratch: device floats,
+ * at least cp_optimizer_scratch_floats(...) long. */
+typedef struct cp_adam_hyper {
+    float lr_emg, lr_glove, reg_emg, reg_glove;
+    float beta1, beta2, eps, grad_scale;
+} cp_adam_hyper;
+size_t cp_optimizer_scratch_floats(const int64_t* numel_host, int32_t n);
+int cp_l2_norms(const float* params_flat, const int64_t* offset_host, const int64_t* numel_host,
+                const int32_t* group_host, const int32_t* l2_host, int32_t n, const cp_adam_hyper* h,
+                float* scratch, float* l2_out, void* stream);
+int cp_l2_adam_step(float* params_flat, const float* grads_flat, float* exp_avg, float* exp_avg_sq,
+                    const int64_t* offset_host, const int64_t* numel_host, const int32_t* group_host,
+                    const int32_t* l2_host, int32_t n, const cp_adam_hyper* h, int64_t step_index,
+                    float* scratch, float* l2_out, void* stream);
+
+/* debug/test access: copy saved activation `layer` (0..8 = post-ReLU pre-BN output of conv1,
+ * conv2, fc1..fc7; rows x C in the internal layout, conv layers position-major [w][c]; 9..12 =
+ * dropout(BN(.)) of fc4..fc7, present only when dp_emg > 0 and the forward ran in training) to f32. */
+int cp_debug_activation(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer,
+                        float* out, void* stream);
+/* BN statistics of `layer` as computed by the last forward: out[4][C] = mean, invstd, scale, shift */
+int cp_debug_bn_stats(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer, float* out,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

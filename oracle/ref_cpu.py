@@ -202,26 +202,48 @@ class OracleModel:
         return F.batch_norm(x, rm, rv, w, b, self.training, 0.1, BN_EPS)
 
     # -- EMG encoder (models.py:248-264, 266-298, 310-315, 319-342) ----------
-    def encode_emg(self, EMG: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    def encode_emg(self, EMG: torch.Tensor, taps: Optional[dict] = None,
+                   dropout_masks: Optional[dict] = None, relu_masks: Optional[dict] = None) -> torch.Tensor:
+        """``taps`` (test aid) receives r0..r8 = post-ReLU pre-BN outputs and the post-BN
+        tensors; ``dropout_masks`` (test aid) {layer 5..8: keep-mask already scaled by
+        1/(1-p)} replaces F.dropout so a device-generated mask can be replayed;
+        ``relu_masks`` (test aid) {layer 0..8: bool mask in this tensor's layout} replaces
+        relu(y) by y*mask, so that a pre-activation that two fp32 implementations round to
+        opposite sides of zero does not make their gradients incomparable."""
         sd = self.sd
+
+        def relu(y, layer):
+            if relu_masks is not None and layer in relu_masks:
+                return y * relu_masks[layer].to(y.dtype)
+            return F.relu(y)
+
         self.shape = tuple(EMG.shape)
         bases = bn_bases(self.adabn)
         x = EMG.reshape(-1, 1, 1, EMG_DIM)
-        x = F.conv2d(x, sd["emg_net.conv_emg.0.weight"], sd["emg_net.conv_emg.0.bias"], padding=1)
-        x = self._bn(F.relu(x), bases[0])
+        x = relu(F.conv2d(x, sd["emg_net.conv_emg.0.weight"], sd["emg_net.conv_emg.0.bias"], padding=1), 0)
+        if taps is not None:
+            taps["r0"] = x
+        x = self._bn(x, bases[0])
         if taps is not None:
             taps["bn1"] = x
-        x = F.conv2d(x, sd["emg_net.conv_emg.3.weight"], sd["emg_net.conv_emg.3.bias"], padding=1)
-        x = self._bn(F.relu(x), bases[1])
+        x = relu(F.conv2d(x, sd["emg_net.conv_emg.3.weight"], sd["emg_net.conv_emg.3.bias"], padding=1), 1)
+        if taps is not None:
+            taps["r1"] = x
+        x = self._bn(x, bases[1])
         x = x.flatten(1)
         if taps is not None:
             taps["bn2"] = x
         dp = float(self.params.get("dp_emg", 0.0))
         for n, (li, drop) in enumerate(zip(LINEAR_IDX, DROPOUT_AFTER)):
-            x = F.linear(x, sd[f"emg_net.linear.{li}.weight"], sd[f"emg_net.linear.{li}.bias"])
-            x = self._bn(F.relu(x), bases[2 + n])
+            x = relu(F.linear(x, sd[f"emg_net.linear.{li}.weight"], sd[f"emg_net.linear.{li}.bias"]), n + 2)
+            if taps is not None:
+                taps[f"r{n + 2}"] = x
+            x = self._bn(x, bases[2 + n])
             if drop:
-                x = F.dropout(x, dp, self.training)
+                if dropout_masks is not None:
+                    x = x * dropout_masks[n + 2]
+                else:
+                    x = F.dropout(x, dp, self.training)
             if taps is not None:
                 taps[f"fc{n + 1}"] = x
         z = F.linear(x, sd["emg_net.last.0.weight"])
@@ -235,7 +257,7 @@ class OracleModel:
     # -- class encoder, contrastive branch (models.py:447-465, 412-414) ------
     def encode_class(self, GLOVE: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         sd = self.sd
-        hot = F.one_hot(labels).to(torch.float32)
+        hot = F.one_hot(labels).to(sd["glove_net.easy.0.weight"].dtype)
         out = F.linear(hot, sd["glove_net.easy.0.weight"], sd["glove_net.easy.0.bias"])
         B, T = GLOVE.shape[0], GLOVE.shape[1]
         d_e = out.shape[-1]
@@ -246,8 +268,9 @@ class OracleModel:
 
     # -- Model.forward (models.py:112-130) ------------------------------------
     def forward(self, EMG: torch.Tensor, GLOVE: torch.Tensor, labels: torch.Tensor,
-                taps: Optional[dict] = None) -> torch.Tensor:
-        ze = self.encode_emg(EMG, taps)
+                taps: Optional[dict] = None, dropout_masks: Optional[dict] = None,
+                relu_masks: Optional[dict] = None) -> torch.Tensor:
+        ze = self.encode_emg(EMG, taps, dropout_masks, relu_masks)
         ze = ze / ze.norm(dim=-1, keepdim=True)
         zc = self.encode_class(GLOVE, labels)
         zc = zc / zc.norm(dim=-1, keepdim=True)
