@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the contrastive sEMG training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one full optimisation step of code/train.py:95-108 on one batch of synthetic
+Ninapro-shaped windows already resident in HBM: group gather -> EMG encoder forward ->
+(N>1: RCCL all-gather of the z embeddings) -> class encoder + 41x41 logits + symmetric CE ->
+backward -> (N>1: RCCL all-reduce of the 8 MB flat gradient) -> L2 regulariser + 2 x Adam.
+Workload at every N: BASELINE config[1] per GPU ("synthetic 12-ch sEMG, 41-class one-hot, batch
+4096, bf16"): 4096 groups = 167,936 windows per GPU per step (weak scaling; config[2] is N=8).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live, inside the timed region, with HIP
+events recorded by the library on the stream the kernels run on (cp_profile_*); `cpu_baseline` is
+the CPU oracle (a port of the reference step, see oracle/ref_cpu.py) timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T = 41
+BEST = dict(d_e=16, lr_emg=9.761e-4, reg_emg=7.103e-5, dp_emg=0.0635,
+            lr_glove=2.653e-3, reg_glove=2.840e-6, dp_glove=0.3817)   # reference data/cross_val_keys.npy[54]
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+
+
+def gemm_model(kind: str, n: int, es: int):
+    """Algorithmic (bytes, flops) of ONE average launch of a GEMM kind over n windows (DESIGN.md
+    'roofline'): fc layers are 768->512 then 6 x 512->512; every activation/gradient element is
+    moved once per kernel that must touch it (BN-barrier model)."""
+    ks = [768] + [512] * 6
+    flops = sum(2.0 * n * 512 * k for k in ks) / 7
+    if kind == "fc_fwd":        # read input, write post-ReLU output
+        byts = sum(n * es * (k + 512) for k in ks) / 7
+    elif kind == "fc_dgrad":    # read g_y, read saved activation (BN-backward sums), write g_v
+        byts = sum(n * es * (512 + 2 * k) for k in ks) / 7
+    else:                       # fc_wgrad: read g_y and the layer input
+        byts = sum(n * es * (512 + k) for k in ks) / 7
+    return byts, flops
+
+
+def cpu_baseline(seconds: float, threads: int):
+    """The reference step on host cores: oracle (pure torch CPU restatement: per-item gather, 3x3
+    Conv2d, per-group CE loop, separate norms, 2 x Adam), B=64 groups (its best CPU batch)."""
+    from oracle import ref_cpu as oc
+    torch.set_num_threads(threads)
+    B = 64
+    sd = oc.init_state_dict(0, 16, adabn=False)
+    m = oc.OracleModel(sd, BEST, adabn=False, requires_grad=True)
+    m.set_train()
+    opts = m.make_optimizers()
+    EMG, GLOVE = oc.synthetic_resident(1234, glove_d=64)
+    db = oc.OracleDB23(EMG, GLOVE)
+    db.set_mode("train")
+    torch.manual_seed(0)
+    emg_rand = oc.make_rand_table(torch.rand(db.TASKS, db.D))
+    glove_rand = oc.make_rand_table(torch.rand(db.TASKS, db.D_g))
+
+    def one(i):
+        idx = torch.randperm(db.D)[:B]
+        e, g, lab = oc.collate(db, emg_rand, glove_rand, idx)
+        m.train_step(e, g, lab.reshape(-1), opts)
+
+    one(0)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        one(n)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n * B * T / dt, unit="windows/s", cores=threads, kind="port",
+                sample=f"{n} steps of B={B} groups ({B * T} windows) in {dt:.1f} s, fp32, oracle/ref_cpu.py")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch_size", type=int, default=4096, help="groups of 41 windows per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--adabn", action="store_true", help="AdaBN instead of stock BN (--no_adabn is BASELINE config 1)")
+    ap.add_argument("--dp_emg", type=float, default=BEST["dp_emg"])
+    ap.add_argument("--cpu_seconds", type=float, default=15.0)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel-kind times to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from contrastiveprosthetics_amd.engine import Engine
+
+    B = args.batch_size
+    N = B * T
+    params = dict(BEST, dp_emg=args.dp_emg)
+    eng = Engine(adabn=args.adabn, dtype=args.dtype, dp_emg=args.dp_emg, device=dev, seed=1000 + rank)
+    eng.init_parameters(seed=42)                      # identical replicas, as DDP broadcasts them
+    eng.workspace(N)
+
+    # synthetic resident table shaped like DB23.EMG_use in --db2 train mode: 41 classes x D rows x 12 ch
+    D = max(20000, B)
+    g = torch.Generator().manual_seed(1234 + rank)
+    mu = torch.randn(T, 1, 12, generator=g)
+    table = (mu + torch.randn(T, D, 12, generator=g)).reshape(T * D, 12).to(dev)
+    emg_rand = (torch.rand(T, D, generator=g).argsort(-1) + torch.arange(T).reshape(T, 1) * D).to(dev)
+    labels = torch.arange(T).repeat(B).to(dev)
+    total = args.warmup + args.steps + 2
+    perms = [torch.randperm(D, generator=g)[:B].to(dev) for _ in range(total)]
+    z_all = torch.empty(world * N, 16, device=dev) if world > 1 else None
+    state = {}
+
+    def step(i):
+        x = eng.gather(table, emg_rand, perms[i], 1)
+        z = eng.encoder_forward(x, training=True)
+        if world > 1:
+            # global-batch z all-gather over xGMI (north_star); under the reference's per-group loss each
+            # rank then scores its own slice of the gathered matrix (parity-neutral)
+            dist.all_gather_into_tensor(z_all, z)
+            z = z_all[rank * N:(rank + 1) * N]
+        out, pred, _ = eng.head(z, labels, 1, want_grad=True)
+        eng.encoder_backward(x)
+        if world > 1:
+            dist.all_reduce(eng.grads.flat)
+        eng.adam_step(params, grad_scale=1.0 / world)
+        state["out"] = out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    gemm_kinds = ["fc_fwd", "fc_dgrad", "fc_wgrad"]
+    eng.profile_enable(gemm_kinds, max_records=64 * (args.steps + 1))
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile_disable()
+    prof = eng.profile_summary()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss, correct = [float(v) for v in state["out"].tolist()]
+
+    if args.breakdown and rank == 0:
+        eng.profile_enable(None, max_records=4096)
+        for i in range(2):
+            step(args.warmup + args.steps + i)
+        eng.profile_disable()
+        bd = eng.profile_summary()
+        tot = sum(v[0] for v in bd.values())
+        for k, (ms, n) in sorted(bd.items(), key=lambda kv: -kv[1][0]):
+            print(f"  {k:14s} {ms / 2:8.3f} ms/step  ({n // 2} launch groups/step, {100 * ms / tot:5.1f} %)", file=sys.stderr)
+        print(f"  sum            {tot / 2:8.3f} ms/step", file=sys.stderr)
+
+    if rank == 0:
+        es = 2 if args.dtype == "bf16" else 4
+        dom = max(gemm_kinds, key=lambda k: prof.get(k, (0.0, 0))[0])
+        ms, launches = prof[dom]
+        avg_s = ms / launches / 1e3
+        byts, flops = gemm_model(dom, N, es)
+        gbs = byts / avg_s / 1e9
+        tfl = flops / avg_s / 1e12
+        mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
+        bound = "hbm" if byts / (HBM_PEAK_GBS * 1e9) >= flops / (mfma_peak * 1e12) else "mfma"
+        roof = dict(bound=bound, kernel=dom, launches=launches, avg_us=avg_s * 1e6,
+                    achieved=gbs if bound == "hbm" else tfl, peak=HBM_PEAK_GBS if bound == "hbm" else mfma_peak,
+                    unit="GB/s" if bound == "hbm" else "TFLOP/s",
+                    frac=(gbs / HBM_PEAK_GBS) if bound == "hbm" else (tfl / mfma_peak), traffic=None,
+                    mfma_tflops=tfl, mfma_frac=tfl / mfma_peak, hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
+                    gemm_ms_per_step={k: prof[k][0] / args.steps for k in gemm_kinds if k in prof})
+        rec = dict(metric="sEMG windows/sec contrastive step, 12-ch Ninapro", value=world * N * args.steps / elapsed,
+                   unit="windows/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype=args.dtype, data="synthetic",
+                   config=dict(workload=f"synthetic 12-ch sEMG, 41-class one-hot, batch {B} groups/GPU "
+                                        f"({N} windows/GPU/step), {'AdaBN' if args.adabn else 'stock BN (--no_adabn)'}, "
+                                        f"dp_emg={args.dp_emg}, d_e=16, random-init weights",
+                               global_batch_groups=world * B, windows_per_step=world * N,
+                               parallelism=f"dp{world}" + (" + z all-gather + flat-gradient all-reduce (RCCL)" if world > 1 else "")),
+                   loss=loss, train_acc=correct / N, roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, threads=min(16, os.cpu_count() or 1))
+            rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

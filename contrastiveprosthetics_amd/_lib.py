@@ -62,9 +62,16 @@ SYMBOLS = {
                               _P(cp_adam_hyper), _fp, _fp, _fp]),
     "cp_l2_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32),
                                   C.c_int32, _P(cp_adam_hyper), C.c_int64, _fp, _fp, _fp]),
+    "cp_profile_enable": (C.c_int, [C.c_uint64, C.c_int32]),
+    "cp_profile_disable": (C.c_int, []),
+    "cp_profile_summary": (C.c_int, [C.c_int32, _P(C.c_double), _P(C.c_int64)]),
     "cp_debug_activation": (C.c_int, [_P(cp_config), _fp, C.c_size_t, C.c_int32, _fp, _fp]),
     "cp_debug_bn_stats": (C.c_int, [_P(cp_config), _fp, C.c_size_t, C.c_int32, _fp, _fp]),
 }
+
+KERNEL_KINDS = ["gather", "prep", "conv1_fwd", "bn_finalize", "conv2_fwd", "fold", "fc_fwd", "dropout", "proj_fwd",
+                "head", "proj_bwd", "bn_bwd", "fc_wgrad", "reduce_slabs", "fc_dgrad", "conv2_wgrad", "conv2_dgrad",
+                "conv1_bwd", "optimizer"]
 
 _lib = None
 

@@ -34,6 +34,69 @@ extern "C" int cp_version(void) { return CP_VERSION; }
 extern "C" const char* cp_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------
+// optional per-kernel-kind timing with HIP events recorded on the launch stream
+// (bench.py's live roofline measurement).  Events are created in cp_profile_enable, never
+// inside a step.  Not thread-safe: one profiled stream at a time.
+// ---------------------------------------------------------------------------------------
+struct Profiler {
+    bool on = false;
+    uint64_t mask = 0;
+    int cap = 0, used = 0;
+    hipEvent_t* ev = nullptr;   // 2 per record
+    int* kind = nullptr;
+};
+static Profiler g_prof;
+
+struct ProfScope {
+    hipStream_t st;
+    int idx;
+    ProfScope(int kind, hipStream_t s) : st(s), idx(-1) {
+        if (g_prof.on && ((g_prof.mask >> kind) & 1) && g_prof.used < g_prof.cap) {
+            idx = g_prof.used++;
+            g_prof.kind[idx] = kind;
+            hipEventRecord(g_prof.ev[2 * idx], st);
+        }
+    }
+    ~ProfScope() {
+        if (idx >= 0) hipEventRecord(g_prof.ev[2 * idx + 1], st);
+    }
+};
+
+extern "C" int cp_profile_enable(uint64_t kind_mask, int32_t max_records) {
+    if (max_records <= 0) return fail(CP_ERR_ARG, "cp_profile_enable args");
+    if (g_prof.cap < max_records) {
+        for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+        delete[] g_prof.ev;
+        delete[] g_prof.kind;
+        g_prof.ev = new hipEvent_t[2 * (size_t)max_records];
+        g_prof.kind = new int[max_records];
+        for (int i = 0; i < 2 * max_records; ++i) CK(hipEventCreate(&g_prof.ev[i]));
+        g_prof.cap = max_records;
+    }
+    g_prof.used = 0;
+    g_prof.mask = kind_mask;
+    g_prof.on = true;
+    return 0;
+}
+extern "C" int cp_profile_disable(void) { g_prof.on = false; return 0; }
+extern "C" int cp_profile_summary(int32_t kind, double* total_ms, int64_t* count) {
+    // caller has synchronised the stream
+    if (!total_ms || !count) return fail(CP_ERR_ARG, "cp_profile_summary args");
+    double t = 0;
+    int64_t n = 0;
+    for (int i = 0; i < g_prof.used; ++i)
+        if (g_prof.kind[i] == kind) {
+            float ms = 0.f;
+            CK(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+            t += ms;
+            ++n;
+        }
+    *total_ms = t;
+    *count = n;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // workspace layout
 // ---------------------------------------------------------------------------------------
 static const int kLayerC[CP_N_BN] = {64, 64, 512, 512, 512, 512, 512, 512, 512};
@@ -46,6 +109,7 @@ struct WS {
     size_t gbuf[2];          // gradient ping-pong, T [N][768]
     size_t dz;               // [N][64] T
     size_t partials;         // f32
+    size_t partials2;        // f32 [REDUCE_SLICES][<=2048]: pre-reduced partial rows
     size_t stats[CP_N_BN];   // [4][C] f32
     size_t coef;             // [3][512] f32
     size_t wc2_f, wc2_d;     // conv2 weights, T [64][192]
@@ -70,6 +134,7 @@ static WS carve(int64_t N, int dtype, float dp) {
     w.dz = take((size_t)N * 64 * es);
     w.partials_floats = (size_t)12 * N + 4 * 1024 * 1024;
     w.partials = take(w.partials_floats * 4);
+    w.partials2 = take((size_t)REDUCE_SLICES * 2048 * 4);
     for (int l = 0; l < CP_N_BN; ++l) w.stats[l] = take(4 * 512 * 4);
     w.coef = take(3 * 512 * 4);
     w.wc2_f = take(64 * 192 * es);
@@ -131,6 +196,7 @@ extern "C" int cp_gather_groups(const float* table, int64_t table_rows, const in
     if (!table || !emg_rand || !perm || !x_out || B <= 0 || V <= 0) return fail(CP_ERR_ARG, "cp_gather_groups args");
     const int64_t total = B * CP_TASKS * V * 3;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    ProfScope ps(CP_K_GATHER, (hipStream_t)stream);
     hipLaunchKernelGGL(gather_groups_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, table, emg_rand, perm, x_out,
                        B, CP_TASKS, (int)V, D, table_rows);
     CKL("gather_groups_kernel");
@@ -144,6 +210,19 @@ static inline int grid_rows(int64_t rows, int rows_per_block, int cap) {
     int64_t g = (rows + rows_per_block - 1) / rows_per_block;
     return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
+
+// fold many partial rows into REDUCE_SLICES rows (parallel) before a single-block finalize
+struct PreReduce {
+    const float* partials;
+    float* scratch;
+    hipStream_t st;
+    const float* operator()(int& nrows, int W) const {
+        if (nrows <= 2 * REDUCE_SLICES) return partials;
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(W / 64, REDUCE_SLICES), dim3(256), 0, st, partials, nrows, W, scratch);
+        nrows = REDUCE_SLICES;
+        return scratch;
+    }
+};
 
 template <typename T>
 static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn_buffers* bn, const float* x,
@@ -159,22 +238,31 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     auto finalize = [&](int l, int nrows, double count) -> int {
+        ProfScope ps(CP_K_BN_FINALIZE, st);
         const int C = kLayerC[l];
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(256), 0, st, partials, nrows, count, p->bn_g[l], p->bn_b[l],
+        const PreReduce pre{partials, (float*)(base + w.partials2), st};
+        const float* pp = batch_stats ? pre(nrows, 2 * C) : partials;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(256), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
                            have_running ? bn->running_mean[l] : nullptr, have_running ? bn->running_var[l] : nullptr, upd,
                            batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats(l), C);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : fail((int)e, "bn_finalize_kernel");
     };
 
-    hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
-    CKL("prep_conv2_kernel");
+    {
+        ProfScope ps(CP_K_PREP, st);
+        hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
+        CKL("prep_conv2_kernel");
+    }
     // conv1
     {
         constexpr int RPP = 256 / (64 / D::EPC);
         const int g = grid_rows(R12, RPP, 2048);
-        hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, act(0), partials, R12);
-        CKL("conv1_fwd_kernel");
+        {
+            ProfScope ps(CP_K_CONV1_FWD, st);
+            hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, act(0), partials, R12);
+            CKL("conv1_fwd_kernel");
+        }
         if (int e = finalize(0, g, (double)R12)) return e;
     }
     // conv2
@@ -184,7 +272,10 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         a.W = base + w.wc2_f; a.F = 64;
         a.C = act(1); a.ldc = 64; a.bias = p->conv2_b; a.relu = 1;
         a.partials = partials; a.a_scale = stats(0) + 2 * 64; a.a_shift = stats(0) + 3 * 64;
-        CK((launch_gemm_nt<T, 128, 64, ALOAD_CONV, EPI_FWD>(a, st)));
+        {
+            ProfScope ps(CP_K_CONV2_FWD, st);
+            CK((launch_gemm_nt<T, 128, 64, ALOAD_CONV, EPI_FWD>(a, st)));
+        }
         if (int e = finalize(1, (int)((R12 + 127) / 128), (double)R12)) return e;
     }
     // fc1..fc7
@@ -194,20 +285,27 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const float *s = stats(Lp) + 2 * kLayerC[Lp], *t = stats(Lp) + 3 * kLayerC[Lp];
         if (drop && Lp >= 5) {
             T* u = (T*)(base + w.u[Lp - 5]);
+            ProfScope ps(CP_K_DROPOUT, st);
             hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N * 512 / D::EPC, 256, 4096)), dim3(256), 0, st,
                                act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg));
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
         }
-        hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(512), dim3(256), 0, st, p->fc_w[i], p->fc_b[i], s, t,
-                           (T*)(base + w.wfc[i]), (float*)(base + w.bfc[i]), 512, K, i == 0 ? 1 : 0);
-        CKL("fold_linear_kernel");
+        {
+            ProfScope ps(CP_K_FOLD, st);
+            hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(512), dim3(256), 0, st, p->fc_w[i], p->fc_b[i], s, t,
+                               (T*)(base + w.wfc[i]), (float*)(base + w.bfc[i]), 512, K, i == 0 ? 1 : 0);
+            CKL("fold_linear_kernel");
+        }
         GemmNTArgs a{};
         a.A = A; a.lda = K; a.M = N; a.K = K;
         a.W = base + w.wfc[i]; a.F = 512;
         a.C = act(L); a.ldc = 512; a.bias = (float*)(base + w.bfc[i]); a.relu = 1;
         a.partials = partials;
-        CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_FWD>(a, st)));
+        {
+            ProfScope ps(CP_K_FC_FWD, st);
+            CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_FWD>(a, st)));
+        }
         if (int e = finalize(L, (int)((N + 127) / 128), (double)N)) return e;
     }
     // projection 512 -> 16 (weights padded to 32 rows)
@@ -217,19 +315,26 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const float *s = stats(Lp) + 2 * 512, *t = stats(Lp) + 3 * 512;
         if (drop) {
             T* u = (T*)(base + w.u[Lp - 5]);
+            ProfScope ps(CP_K_DROPOUT, st);
             hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N * 512 / D::EPC, 256, 4096)), dim3(256), 0, st,
                                act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg));
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
         }
-        hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(32), dim3(256), 0, st, p->last_w, (const float*)nullptr, s, t,
-                           (T*)(base + w.wlast), (float*)(base + w.blast), CP_D_E, 512, 0);
-        CKL("fold_linear_kernel(last)");
+        {
+            ProfScope ps(CP_K_FOLD, st);
+            hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(32), dim3(256), 0, st, p->last_w, (const float*)nullptr, s, t,
+                               (T*)(base + w.wlast), (float*)(base + w.blast), CP_D_E, 512, 0);
+            CKL("fold_linear_kernel(last)");
+        }
         GemmNTArgs a{};
         a.A = A; a.lda = 512; a.M = N; a.K = 512;
         a.W = base + w.wlast; a.F = 32;
         a.C = z; a.ldc = CP_D_E; a.f_valid = CP_D_E; a.bias = (float*)(base + w.blast);
-        CK((launch_gemm_nt<T, 128, 32, ALOAD_PLAIN, EPI_PLAIN_F32>(a, st)));
+        {
+            ProfScope ps(CP_K_PROJ_FWD, st);
+            CK((launch_gemm_nt<T, 128, 32, ALOAD_PLAIN, EPI_PLAIN_F32>(a, st)));
+        }
     }
     return 0;
 }
@@ -258,6 +363,7 @@ extern "C" int cp_head(const cp_config* cfg, const cp_params* p, const float* z,
     hipStream_t st = (hipStream_t)stream;
     unsigned char* base = (unsigned char*)ws;
     const size_t es = cfg->dtype == CP_BF16 ? 2 : 4;
+    ProfScope ps(CP_K_HEAD, st);
     if (want_grad) CK(hipMemsetAsync(base + w.dz, 0, (size_t)cfg->n_windows * 64 * es, st));
     HeadArgs a{};
     a.z = z; a.easy_w = p->easy_w; a.easy_b = p->easy_b; a.labels = labels;
@@ -269,7 +375,10 @@ extern "C" int cp_head(const cp_config* cfg, const cp_params* p, const float* z,
     else
         hipLaunchKernelGGL((head_kernel<float>), dim3(blocks), dim3(256), 0, st, a);
     CKL("head_kernel");
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, a.partials, blocks, n_groups, p->easy_w, p->easy_b,
+    int nr = blocks;
+    const PreReduce pre{a.partials, (float*)(base + w.partials2), st};
+    const float* pp = pre(nr, HEAD_PART);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, n_groups, p->easy_w, p->easy_b,
                        want_grad, loss_correct, want_grad ? grads->easy_w : nullptr, want_grad ? grads->easy_b : nullptr);
     CKL("head_finalize_kernel");
     return 0;
@@ -306,28 +415,33 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     const int tiles_n = (int)((N + 127) / 128);
+    const PreReduce pre{partials, (float*)(base + w.partials2), st};
 
-    for (int i = 0; i < CP_N_FC; ++i) {
-        const int K = fcK(i);
-        hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(256), dim3(256), 0, st, p->fc_w[i], (T*)(base + w.wfc_t[i]), 512, K, 512,
-                           i == 0 ? 1 : 0);
+    {
+        ProfScope ps(CP_K_PREP, st);
+        for (int i = 0; i < CP_N_FC; ++i) {
+            const int K = fcK(i);
+            hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(256), dim3(256), 0, st, p->fc_w[i], (T*)(base + w.wfc_t[i]), 512, K, 512,
+                               i == 0 ? 1 : 0);
+        }
+        hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(64), dim3(256), 0, st, p->last_w, (T*)(base + w.wlast_t), CP_D_E, 512, 64, 0);
+        CKL("transpose_w_kernel");
     }
-    hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(64), dim3(256), 0, st, p->last_w, (T*)(base + w.wlast_t), CP_D_E, 512, 64, 0);
-    CKL("transpose_w_kernel");
 
     T* dz = (T*)(base + w.dz);
     T* cur = (T*)(base + w.gbuf[0]);
     T* nxt = (T*)(base + w.gbuf[1]);
     // ---- projection ------------------------------------------------------------------
     {
+        ProfScope ps(CP_K_PROJ_BWD, st);
         const T* Y = drop ? (const T*)(base + w.u[3]) : act(8);
         const float *s = nullptr, *t = nullptr;
         float* dzsum = (float*)(base + w.dzsum);
         if (!drop) {
             s = stats(8) + 2 * 512; t = stats(8) + 3 * 512;
-            const int gb = grid_rows(N, 256 / (CP_D_E / D::EPC), 512);
+            const int gb = grid_rows(N, 256 / (CP_D_E / D::EPC), 64);
             hipLaunchKernelGGL((colsum_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, dz, partials, N, 64, CP_D_E);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, partials, gb, CP_D_E, dzsum);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, partials, gb, CP_D_E, dzsum);  // 16 columns: tiny
             CKL("colsum(dz)");
         }
         GemmTNArgs ta{};
@@ -347,13 +461,20 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     // ---- fc7 .. fc1 --------------------------------------------------------------------
     for (int L = 8; L >= 2; --L) {
         const int i = L - 2, Lp = L - 1, K = fcK(i);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(256), 0, st, partials, tiles_n, (double)N, stats(L), coef,
-                           g->bn_g[L], g->bn_b[L], 512, 1);
-        CKL("bn_bwd_finalize_kernel");
-        const int gb = grid_rows(N, 256 / (512 / D::EPC), 1024);
-        hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(2), dim3(256), 0, st, partials, gb, 512, g->fc_b[i]);
-        CKL("bn_relu_bwd_kernel");
+        {
+            ProfScope ps(CP_K_BN_BWD, st);
+            int nr = tiles_n;
+            const float* pp = pre(nr, 2 * 512);
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(256), 0, st, pp, nr, (double)N, stats(L), coef,
+                               g->bn_g[L], g->bn_b[L], 512, 1);
+            CKL("bn_bwd_finalize_kernel");
+            const int gb = grid_rows(N, 256 / (512 / D::EPC), 2048);
+            hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
+            nr = gb;
+            pp = pre(nr, 512);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(2), dim3(256), 0, st, pp, nr, 512, g->fc_b[i]);
+            CKL("bn_relu_bwd_kernel");
+        }
         const bool in_drop = drop && Lp >= 5;
         const T* Y = in_drop ? (const T*)(base + w.u[Lp - 5]) : act(Lp);
         const float* s = in_drop ? nullptr : stats(Lp) + 2 * kLayerC[Lp];
@@ -362,51 +483,78 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
         int S;
         split_rows(N, 32, &S, &ta.rows_per_split);
-        CK((launch_gemm_tn<T, 128, 128, YLOAD_PLAIN>(ta, S, st)));
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
-                           i == 0 ? 1 : 0);
-        CKL("reduce_slabs(fc)");
+        {
+            ProfScope ps(CP_K_FC_WGRAD, st);
+            CK((launch_gemm_tn<T, 128, 128, YLOAD_PLAIN>(ta, S, st)));
+        }
+        {
+            ProfScope ps(CP_K_REDUCE_SLABS, st);
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
+                               i == 0 ? 1 : 0);
+            CKL("reduce_slabs(fc)");
+        }
         GemmNTArgs a{};
         a.A = cur; a.lda = 512; a.M = N; a.K = 512;
         a.W = base + w.wfc_t[i]; a.F = K;
         a.C = nxt; a.ldc = K; a.R = act(Lp); a.ldr = K; a.partials = partials;
         if (in_drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
-        CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_DGRAD>(a, st)));
+        {
+            ProfScope ps(CP_K_FC_DGRAD, st);
+            CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_DGRAD>(a, st)));
+        }
         T* tmp = cur; cur = nxt; nxt = tmp;
     }
     // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
     {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, tiles_n, (double)R12, stats(1), coef,
-                           g->bn_g[1], g->bn_b[1], 64, 12);
-        CKL("bn_bwd_finalize_kernel(conv2)");
-        const int gb = grid_rows(R12, 256 / (64 / D::EPC), 1024);
-        hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, partials, gb, 64, g->conv2_b);
-        CKL("bn_relu_bwd_kernel(conv2)");
+        {
+            ProfScope ps(CP_K_BN_BWD, st);
+            int nr = tiles_n;
+            const float* pp = pre(nr, 2 * 768);
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, (double)R12, stats(1), coef,
+                               g->bn_g[1], g->bn_b[1], 64, 12);
+            CKL("bn_bwd_finalize_kernel(conv2)");
+            const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
+            hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
+            nr = gb;
+            pp = pre(nr, 64);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, pp, nr, 64, g->conv2_b);
+            CKL("bn_relu_bwd_kernel(conv2)");
+        }
         GemmTNArgs ta{};
         ta.X = cur; ta.ldx = 64; ta.Y = act(0); ta.ldy = 64; ta.slabs = slabs; ta.M = R12; ta.P = 64; ta.Q = 192;
         ta.y_scale = stats(0) + 2 * 64; ta.y_shift = stats(0) + 3 * 64;
         int S;
         split_rows(R12, 256, &S, &ta.rows_per_split);
-        CK((launch_gemm_tn<T, 64, 64, YLOAD_CONV>(ta, S, st)));
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, slabs, S, 64, 192, 64, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2);
-        CKL("reduce_slabs(conv2)");
+        {
+            ProfScope ps(CP_K_CONV2_WGRAD, st);
+            CK((launch_gemm_tn<T, 64, 64, YLOAD_CONV>(ta, S, st)));
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, slabs, S, 64, 192, 64, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2);
+            CKL("reduce_slabs(conv2)");
+        }
         GemmNTArgs a{};
         a.A = cur; a.lda = 64; a.M = R12; a.K = 192;
         a.W = base + w.wc2_d; a.F = 64;
         a.C = nxt; a.ldc = 64; a.R = act(0); a.ldr = 64; a.partials = partials;
-        CK((launch_gemm_nt<T, 128, 64, ALOAD_CONV, EPI_DGRAD>(a, st)));
+        {
+            ProfScope ps(CP_K_CONV2_DGRAD, st);
+            CK((launch_gemm_nt<T, 128, 64, ALOAD_CONV, EPI_DGRAD>(a, st)));
+        }
     }
     // ---- conv1 -----------------------------------------------------------------------------
     {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int)((R12 + 127) / 128), (double)R12,
-                           stats(0), coef, g->bn_g[0], g->bn_b[0], 64, 1);
+        ProfScope ps(CP_K_CONV1_BWD, st);
+        int nr = (int)((R12 + 127) / 128);
+        const float* pp = pre(nr, 2 * 64);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, (double)R12, stats(0), coef, g->bn_g[0],
+                           g->bn_b[0], 64, 1);
         CKL("bn_bwd_finalize_kernel(conv1)");
         constexpr int RPP = 256 / (64 / D::EPC);
-        const int gb = grid_rows(R12, RPP, 1024);
+        const int gb = grid_rows(R12, RPP, 2048);
         hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, act(0), x, coef, partials, R12);
-        hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, gb, g->conv1_w, g->conv1_b);
+        nr = gb;
+        pp = pre(nr, 4 * 64);
+        hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, g->conv1_w, g->conv1_b);
         CKL("conv1_bwd_kernel");
     }
     return 0;
@@ -482,6 +630,7 @@ extern "C" int cp_l2_adam_step(float* params_flat, const float* grads_flat, floa
     a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.grad_scale = h->grad_scale;
     a.bc1 = (float)(1.0 - pow((double)h->beta1, (double)step_index));
     a.bc2 = (float)(1.0 - pow((double)h->beta2, (double)step_index));
+    ProfScope ps(CP_K_OPT, (hipStream_t)stream);
     if (int e = launch_norms(a, scratch, l2_out, (hipStream_t)stream)) return e;
     hipLaunchKernelGGL(adam_kernel, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);
     CKL("adam_kernel");

@@ -29,7 +29,7 @@ struct HeadArgs {
     int32_t* pred;           // [G][41]
     float* partials;         // [blocks][HEAD_PART] : loss sum, correct count, dE_hat[41][16]
 };
-#define HEAD_PART (2 + HEAD_T * HEAD_D)
+#define HEAD_PART 704        // 2 + 41*16 = 658 used, padded to a multiple of 64 for reduce_rows_kernel
 
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
@@ -87,26 +87,26 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
         // ---- row pass: lane i owns logits[i][:] --------------------------------------
-        float l[HEAD_T];
+        // (the 41 logits of the row live in the wave's LDS tile, not in 41 registers: lanes >= 41
+        //  shadow row 0 and never write)
         float mx = -INFINITY, lt = 0.f;
         int arg = 0;
-#pragma unroll
+#pragma unroll 4
         for (int j = 0; j < HEAD_T; ++j) {
             const float* e = Eh[Cls[wave][j]];
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < HEAD_D; ++d) s = fmaf(zh[d], e[d], s);
-            l[j] = s;
+            if (act) Ls[wave][lane][j] = s;
             if (s > mx) { mx = s; arg = j; }
             if (j == tgt) lt = s;
         }
+        __builtin_amdgcn_wave_barrier();
         float se = 0.f;
-#pragma unroll
-        for (int j = 0; j < HEAD_T; ++j) se += __expf(l[j] - mx);
-        const float lse = mx + __logf(se);
+#pragma unroll 4
+        for (int j = 0; j < HEAD_T; ++j) se += expf(Ls[wave][li][j] - mx);
+        const float lse = mx + logf(se);
         if (act) {
-#pragma unroll
-            for (int j = 0; j < HEAD_T; ++j) Ls[wave][lane][j] = l[j];
             loss_acc += lse - lt;
             corr_acc += (arg == tgt) ? 1.f : 0.f;
             a.pred[g * HEAD_T + lane] = arg;
@@ -119,12 +119,12 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
         // ---- column pass: lane j owns logits[:][j] -----------------------------------
         {
             float cm = -INFINITY;
-#pragma unroll
+#pragma unroll 4
             for (int i = 0; i < HEAD_T; ++i) cm = fmaxf(cm, Ls[wave][i][li]);
             float cs = 0.f;
-#pragma unroll
-            for (int i = 0; i < HEAD_T; ++i) cs += __expf(Ls[wave][i][li] - cm);
-            const float clse = cm + __logf(cs);
+#pragma unroll 4
+            for (int i = 0; i < HEAD_T; ++i) cs += expf(Ls[wave][i][li] - cm);
+            const float clse = cm + logf(cs);
             if (act) {
                 Cl[wave][lane] = clse;
                 loss_acc += clse - Ls[wave][tgt][lane];      // column j's target row is labels[j]
@@ -137,21 +137,20 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
 #pragma unroll
             for (int d = 0; d < HEAD_D; ++d) dzh[d] = 0.f;
             const float inv_se = 1.0f / se;
-#pragma unroll
+#pragma unroll 4
             for (int j = 0; j < HEAD_T; ++j) {
-                float dl = __expf(l[j] - mx) * inv_se + __expf(l[j] - Cl[wave][j]);
+                const float lj = Ls[wave][li][j];
+                float dl = expf(lj - mx) * inv_se + expf(lj - Cl[wave][j]);
                 dl -= (j == tgt) ? 1.f : 0.f;
                 dl -= (Tg[j] == li) ? 1.f : 0.f;
                 dl *= cscale;
                 const float* e = Eh[Cls[wave][j]];
 #pragma unroll
                 for (int d = 0; d < HEAD_D; ++d) dzh[d] = fmaf(dl, e[d], dzh[d]);
-                l[j] = dl;
+                if (act) Ls[wave][lane][j] = dl;      // own row, read above: the tile now holds dlogits
             }
             __builtin_amdgcn_wave_barrier();
             if (act) {
-#pragma unroll
-                for (int j = 0; j < HEAD_T; ++j) Ls[wave][lane][j] = l[j];
                 // through the normalisation: dz = (dzh - zh (zh.dzh)) / |z|
                 float dot = 0.f;
 #pragma unroll

@@ -332,6 +332,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     }
 }
 
+// first stage of every partial-sum reduction: fold nrows partial rows of width W into
+// REDUCE_SLICES rows (row r goes to slice r % REDUCE_SLICES), so that the single-block finalize
+// kernels never walk more than REDUCE_SLICES rows.  grid (W/64, REDUCE_SLICES), 256 threads.
+#define REDUCE_SLICES 32
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, int nrows, int W,
+                                                          float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    for (int r = blockIdx.y + REDUCE_SLICES * g; r < nrows; r += REDUCE_SLICES * 4) s += in[(int64_t)r * W + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0) out[(int64_t)blockIdx.y * W + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
 // out[c] = sum_rows partials[row][c]  (f64 accumulation; one thread per column)
 __global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nrows, int C, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

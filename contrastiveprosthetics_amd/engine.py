@@ -121,6 +121,7 @@ class Engine:
         self.exp_avg = torch.zeros_like(self.values.flat)
         self.exp_avg_sq = torch.zeros_like(self.values.flat)
         self.adam_steps = 0
+        self.num_batches_tracked = 0
         self.running: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         if not self.adabn:
             for b in bn_bases(False):
@@ -198,10 +199,16 @@ class Engine:
         _lib.check(self.lib.cp_encoder_forward(C.byref(cfg), C.byref(self._p), bn, x.data_ptr(), ws, nb, z.data_ptr(),
                                                self._stream()), "cp_encoder_forward")
         if training and not self.adabn:
-            for b in bn_bases(False):
-                self.running[b + ".num_batches_tracked"] += 1
+            self.num_batches_tracked += 1          # host counter; materialised by running_state()
         self._last = (n, training)
         return z
+
+    def running_state(self) -> "OrderedDict[str, torch.Tensor]":
+        """BN buffers as the reference's state_dict holds them (running_mean/var/num_batches_tracked)."""
+        for k, v in self.running.items():
+            if k.endswith("num_batches_tracked"):
+                v.fill_(self.num_batches_tracked)
+        return self.running
 
     def head(self, z: torch.Tensor, labels: torch.Tensor, V: int, want_grad: bool, want_logits: bool = False):
         n = z.shape[0]
@@ -282,10 +289,53 @@ class Engine:
                    "cp_debug_bn_stats")
         return out
 
+    # ------------------------------------------------------------------ profiling (bench.py)
+    def profile_enable(self, kinds=None, max_records: int = 4096):
+        names = _lib.KERNEL_KINDS
+        mask = 0
+        for k in (kinds or names):
+            mask |= 1 << names.index(k)
+        _lib.check(self.lib.cp_profile_enable(mask, max_records), "cp_profile_enable")
+
+    def profile_disable(self):
+        self.lib.cp_profile_disable()
+
+    def profile_summary(self) -> Dict[str, Tuple[float, int]]:
+        """{kind: (total ms, launches)} of the records taken since profile_enable; sync first."""
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for i, name in enumerate(_lib.KERNEL_KINDS):
+            ms, n = C.c_double(0), C.c_int64(0)
+            _lib.check(self.lib.cp_profile_summary(i, C.byref(ms), C.byref(n)), "cp_profile_summary")
+            if n.value:
+                out[name] = (ms.value, n.value)
+        return out
+
     # ------------------------------------------------------------------ state
+    def init_parameters(self, seed: int):
+        """PyTorch-default initialisation of code/models.py:67-85 (kaiming-uniform a=sqrt(5), i.e.
+        U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases; BN gamma 1, beta 0)."""
+        g = torch.Generator().manual_seed(seed)
+        bns = set(bn_bases(self.adabn))
+        for k, shp in self.specs.items():
+            base = k.rsplit(".", 1)[0]
+            if base in bns:
+                self.values.views[k].fill_(1.0 if k.endswith("weight") else 0.0)
+                continue
+            wshape = shp if k.endswith("weight") else self.specs[base + ".weight"]
+            bound = 1.0 / float(np.prod(wshape[1:])) ** 0.5
+            self.values.views[k].copy_(((torch.rand(shp, generator=g) * 2 - 1) * bound).to(self.device))
+        for k, v in self.running.items():
+            if k.endswith("running_var"):
+                v.fill_(1.0)
+            else:
+                v.zero_()
+
     def load_named(self, sd: Dict[str, torch.Tensor]):
         for k in self.specs:
             self.values.views[k].copy_(sd[k].to(self.device, torch.float32))
         for k in self.running:
             if k in sd:
                 self.running[k].copy_(sd[k].to(self.device))
+                if k.endswith("num_batches_tracked"):
+                    self.num_batches_tracked = int(sd[k])

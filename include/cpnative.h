@@ -137,6 +137,21 @@ int cp_l2_adam_step(float* params_flat, const float* grads_flat, float* exp_avg,
                     const int32_t* l2_host, int32_t n, const cp_adam_hyper* h, int64_t step_index,
                     float* scratch, float* l2_out, void* stream);
 
+/* Optional timing of kernel groups with HIP events recorded on the launch stream (used by
+ * bench.py for the live roofline figure).  cp_profile_enable creates the events (never done inside
+ * a step); every profiled launch group then records a start/stop pair until max_records are used.
+ * cp_profile_summary (after the caller synchronised the stream) sums the elapsed times of one kind. */
+enum {
+    CP_K_GATHER = 0, CP_K_PREP = 1, CP_K_CONV1_FWD = 2, CP_K_BN_FINALIZE = 3, CP_K_CONV2_FWD = 4,
+    CP_K_FOLD = 5, CP_K_FC_FWD = 6, CP_K_DROPOUT = 7, CP_K_PROJ_FWD = 8, CP_K_HEAD = 9,
+    CP_K_PROJ_BWD = 10, CP_K_BN_BWD = 11, CP_K_FC_WGRAD = 12, CP_K_REDUCE_SLABS = 13,
+    CP_K_FC_DGRAD = 14, CP_K_CONV2_WGRAD = 15, CP_K_CONV2_DGRAD = 16, CP_K_CONV1_BWD = 17,
+    CP_K_OPT = 18, CP_K_COUNT = 19
+};
+int cp_profile_enable(uint64_t kind_mask, int32_t max_records);
+int cp_profile_disable(void);
+int cp_profile_summary(int32_t kind, double* total_ms, int64_t* count);
+
 /* debug/test access: copy saved activation `layer` (0..8 = post-ReLU pre-BN output of conv1,
  * conv2, fc1..fc7; rows x C in the internal layout, conv layers position-major [w][c]; 9..12 =
  * dropout(BN(.)) of fc4..fc7, present only when dp_emg > 0 and the forward ran in training) to f32. */

@@ -63,7 +63,7 @@ def test_forward_f32_layers(adabn, B):
     assert np.array_equal(pred.cpu().numpy(), logits_ref.argmax(-1).numpy())
     assert out[1].item() / (B * T) == pytest.approx(m.corrects[0], abs=1e-6)
     if not adabn:
-        for k, v in e.running.items():
+        for k, v in e.running_state().items():
             if v.dtype.is_floating_point:
                 np.testing.assert_allclose(v.cpu().numpy(), m.sd[k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
             else:
@@ -327,9 +327,10 @@ def test_eval_stock_bn_running_stats_golden(golden_dir):
     e = make_engine(sd, False, "f32")
     for s in range(3):
         e.encoder_forward(randn(200 + s, (4, T, 1, 1, 12)).reshape(-1, 12).cuda(), training=True)
+    running = e.running_state()
     for k in g.files:
         if k.startswith("buf/"):
-            v = e.running[k[4:]].cpu().numpy()
+            v = running[k[4:]].cpu().numpy()
             np.testing.assert_allclose(v, g[k], rtol=1e-4, atol=1e-6, err_msg=k)
     B, V = 2, 25
     label = torch.arange(T).repeat(B)
