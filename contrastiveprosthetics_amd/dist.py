@@ -1,0 +1,82 @@
+"""One-process-per-GPU data parallelism over torch.distributed (backend "nccl" == RCCL over xGMI on
+ROCm; "gloo" for the CPU plumbing tests).  The reference has no distributed code at all; this is the
+multi-GPU design of SURVEY.md 8e:
+
+* groups (the batch axis) are sharded over ranks -- the 41x41 contrastive blocks are independent;
+* the 8 MB flat gradient buffer is summed with ONE all-reduce per step and averaged inside the fused
+  Adam kernel (grad_scale = 1/world); the L2 regulariser is applied after the reduction, once;
+* the z embeddings (N_local x 16 f32) can be all-gathered into the global-batch matrix; under the
+  reference's per-group loss every rank then scores its own row slice (parity-neutral);
+* BatchNorm statistics stay local to a rank (standard DDP semantics == the reference at B_local).
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as td
+
+
+def world_size() -> int:
+    return td.get_world_size() if td.is_available() and td.is_initialized() else 1
+
+
+def rank() -> int:
+    return td.get_rank() if td.is_available() and td.is_initialized() else 0
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int]:
+    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  No-op for 1 process."""
+    w = int(os.environ.get("WORLD_SIZE", "1"))
+    if w <= 1 or td.is_initialized():
+        return rank(), world_size()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        td.init_process_group(backend)
+    return rank(), world_size()
+
+
+def shutdown():
+    if td.is_available() and td.is_initialized():
+        td.destroy_process_group()
+
+
+def shard_range(n_items: int, r: int, w: int) -> Tuple[int, int]:
+    """Contiguous, balanced [start, end) of n_items for rank r of w (first n % w ranks get one more)."""
+    base, extra = divmod(n_items, w)
+    start = r * base + min(r, extra)
+    return start, start + base + (1 if r < extra else 0)
+
+
+def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
+    if world_size() > 1:
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+    return flat
+
+
+def broadcast_(flat: torch.Tensor, src: int = 0) -> torch.Tensor:
+    if world_size() > 1:
+        td.broadcast(flat, src)
+    return flat
+
+
+def all_gather_rows(local: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """(n_local, d) per rank -> (world*n_local, d), rank-major.  Equal n_local on every rank."""
+    w = world_size()
+    if w == 1:
+        return local
+    if out is None:
+        out = torch.empty((w * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    td.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def local_rows(gathered: torch.Tensor, n_local: int) -> torch.Tensor:
+    r = rank()
+    return gathered[r * n_local:(r + 1) * n_local]

@@ -99,6 +99,19 @@ def _params_struct(store: FlatStore, adabn: bool) -> _lib.cp_params:
     return p
 
 
+def gather_groups(table: torch.Tensor, emg_rand: torch.Tensor, perm: torch.Tensor, V: int) -> torch.Tensor:
+    """cp_gather_groups: (B,41,V,12) f32 = table[(emg_rand[t, perm[b]] * V + v)]  (code/utils.py:51-64)."""
+    lib = _lib.load()
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1] == 12
+    assert emg_rand.dtype == torch.int64 and emg_rand.is_contiguous() and perm.dtype == torch.int64
+    B = perm.numel()
+    out = torch.empty(B, CP_TASKS, V, 12, dtype=torch.float32, device=table.device)
+    _lib.check(lib.cp_gather_groups(table.data_ptr(), table.shape[0], emg_rand.data_ptr(), emg_rand.shape[1],
+                                    perm.contiguous().data_ptr(), B, V, out.data_ptr(),
+                                    torch.cuda.current_stream(table.device).cuda_stream), "cp_gather_groups")
+    return out
+
+
 class Engine:
     def __init__(self, adabn: bool = True, dtype: str = "bf16", dp_emg: float = 0.0, device="cuda",
                  d_e: int = CP_D_E, seed: int = 0):

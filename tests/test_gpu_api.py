@@ -1,0 +1,181 @@
+"""The reference-shaped Python surface (Model / DB23 / TaskWrapper / train.py) on a real MI355X,
+written the way code that uses the reference would be written, checked against the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as oc
+
+pytestmark = pytest.mark.gpu
+
+BEST = dict(d_e=16, lr_emg=9.761e-4, reg_emg=7.103e-5, dp_emg=0.0, lr_glove=2.653e-3, reg_glove=2.840e-6, dp_glove=0.0)
+T = 41
+
+
+def randn(seed, shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def fresh_model(adabn, sd=None, dtype="f32", params=BEST):
+    from contrastiveprosthetics_amd.models import Model
+    m = Model(dict(params), adabn=adabn, device="cuda", dtype=dtype).to(torch.float32)
+    if sd is not None:
+        m.load_state_dict(sd, strict=True)
+    return m
+
+
+@pytest.mark.parametrize("adabn", [False, True])
+def test_state_dict_contract(adabn):
+    m = fresh_model(adabn)
+    ref = oc.init_state_dict(1, 16, adabn)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert len(sd) == (41 if adabn else 68)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape) and sd[k].dtype == ref[k].dtype, k
+    m.load_state_dict(ref, strict=True)                      # a reference checkpoint loads
+    for k in ref:
+        assert torch.equal(m.state_dict()[k].cpu(), ref[k]), k
+    assert len(list(m.emg_net.parameters())) == 37 and len(list(m.glove_net.parameters())) == 3
+    assert sum(p.numel() for p in m.parameters()) == 2027617
+    with pytest.raises(NotImplementedError):
+        from contrastiveprosthetics_amd.models import Model
+        Model(dict(BEST), prediction=True)
+
+
+@pytest.mark.parametrize("adabn", [False, True])
+def test_reference_style_step_matches_oracle(adabn):
+    """code/train.py:95-108 verbatim (two torch Adams, loss + l2, autograd) on top of the HIP kernels."""
+    sd = oc.init_state_dict(11, 16, adabn)      # (seed/data pair without a ReLU sign coincidence, see parity tests)
+    model = fresh_model(adabn, sd)
+    opt_e = torch.optim.Adam(model.emg_net.parameters(), lr=BEST["lr_emg"], weight_decay=0)
+    opt_g = torch.optim.Adam(model.glove_net.parameters(), lr=BEST["lr_glove"], weight_decay=0)
+    model.set_train()
+    o = oc.OracleModel(sd, BEST, adabn=adabn, requires_grad=True)
+    o.set_train()
+    EMG = randn(101, (8, T, 1, 1, 12))
+    label = torch.arange(T).repeat(8)
+    ref_logits = o.forward(EMG, torch.zeros(8, T, 20), label)
+    ref_loss = o.loss(ref_logits, label)
+    ref_l2 = o.l2()
+    (ref_loss + ref_l2).backward()
+
+    logits = model.forward(EMG.cuda(), torch.zeros(8, T, 20).cuda(), label.cuda())
+    loss = model.loss(logits, label.cuda())
+    assert tuple(loss.shape) == (1,)
+    assert loss.item() == pytest.approx(ref_loss.item(), rel=2e-6)
+    l2 = model.l2()
+    assert l2.item() == pytest.approx(ref_l2.item(), rel=2e-6)
+    loss = loss + l2
+    opt_e.zero_grad(set_to_none=True)
+    opt_g.zero_grad(set_to_none=True)
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref_logits.detach().numpy(), atol=2e-5, rtol=0)
+    named = dict(model.named_parameters())
+    assert named["logit_scale"].grad is None
+    for k, v in o.sd.items():
+        if v.requires_grad and k != "logit_scale":
+            got = named[k].grad.cpu()
+            scale = float(v.grad.abs().max()) + 1e-12
+            assert float((got - v.grad).abs().max()) / scale < 5e-3, k      # ReLU sign noise allowed (see parity tests)
+    opt_e.step()
+    opt_g.step()
+    assert model.correct() == pytest.approx(o.corrects[0], abs=1e-6)
+
+
+def test_fused_step_equals_reference_style_step():
+    adabn = False
+    sd = oc.init_state_dict(15, 16, adabn)
+    a, b = fresh_model(adabn, sd), fresh_model(adabn, sd)
+    opt_e = torch.optim.Adam(a.emg_net.parameters(), lr=BEST["lr_emg"], weight_decay=0)
+    opt_g = torch.optim.Adam(a.glove_net.parameters(), lr=BEST["lr_glove"], weight_decay=0)
+    a.set_train()
+    b.set_train()
+    for s in range(2):
+        EMG = randn(400 + s, (8, T, 1, 1, 12)).cuda()
+        label = torch.arange(T).repeat(8).cuda()
+        la = a.loss(a.forward(EMG, None, label), label)
+        (la + a.l2()).backward()
+        opt_e.step()
+        opt_g.step()
+        opt_e.zero_grad(set_to_none=True)
+        opt_g.zero_grad(set_to_none=True)
+        lb = b.loss(b.forward(EMG, None, label), label)
+        b.backward()
+        b.optimizer_step()
+        assert la.item() == pytest.approx(lb.item(), rel=1e-6)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            moved = float((sa[k].cpu() - sd[k]).abs().max()) + 1e-12
+            assert float((sa[k] - sb[k]).abs().max()) <= 2e-3 * moved + 1e-9, k
+        else:
+            assert int(sa[k]) == int(sb[k]) == 2
+
+
+def test_eval_vote_through_model_api(golden_dir):
+    g = np.load(os.path.join(golden_dir, "eval_vote_B2_adabn.npz"))
+    model = fresh_model(True, oc.init_state_dict(int(g["weight_seed"]), 16, True))
+    model.set_test()
+    EMG = randn(int(g["emg_seed"]), (2, T, 25, 1, 12)).cuda()
+    label = torch.arange(T).repeat(2).cuda()
+    with torch.no_grad():
+        logits = model.forward(EMG, torch.zeros(2, T, 20).cuda(), label)
+        loss = model.loss(logits, label)
+    assert tuple(logits.shape) == (50, 41, 41)
+    assert loss.item() == pytest.approx(float(g["eval_loss"]), rel=2e-6)
+    v = model.voting_raw()
+    assert v.shape == (2, 249)                               # reference quirk: range(1, 250)
+    np.testing.assert_allclose(v[:, :24], g["vote"], atol=1e-6)
+    assert np.all(v[:, 24:] == v[:, 24:25])
+    assert np.array_equal(model.y_pred_raw(), g["y_pred"])
+    assert np.array_equal(model.y_true_raw(), np.tile(np.arange(T), (2, 1)))
+    assert model.correct() == pytest.approx(float(g["acc"]), abs=1e-6)
+
+
+def test_db23_taskwrapper_against_oracle():
+    from contrastiveprosthetics_amd.load import DB23
+    from contrastiveprosthetics_amd.utils import TaskWrapper
+    db = DB23(db2=False)
+    db.load_synthetic(seed=1234, glove_d=64)
+    EMG, GLOVE = oc.synthetic_resident(1234, glove_d=64)
+    assert torch.equal(db.EMG.cpu(), EMG) and torch.equal(db.GLOVE.cpu(), GLOVE)
+    odb = oc.OracleDB23(EMG, GLOVE)
+    tw = TaskWrapper(db)
+    for mode, V, D in (("train", 1, 1800), ("val", 25, 24), ("test", 25, 48)):
+        getattr(tw, "set_" + mode)()
+        odb.set_mode(mode)
+        assert (db.D, len(tw), len(db), db.TASKS, db.PEOPLE, db.REPS) == (D, D, 41 * D, 41, 6, odb.REPS)
+        assert torch.equal(db.EMG_use.cpu(), odb.EMG_use) and torch.equal(db.tensor.cpu(), odb.tensor)
+        er = tw.emg_rand.cpu()
+        for t in (0, 17, 40):                                # every row a permutation of its class's range
+            assert np.array_equal(np.sort(er[t].numpy()), np.arange(t * D, (t + 1) * D))
+        perm = torch.tensor([5, 0, D - 1, 3], device="cuda")
+        E, G, L = tw.batch(perm)
+        items = [tw[int(i)] for i in perm]
+        assert torch.equal(E, torch.stack([i[0] for i in items]))
+        assert torch.equal(G, torch.stack([i[1] for i in items]))
+        assert torch.equal(L, torch.stack([i[2] for i in items]))
+        assert tuple(E.shape) == (4, 41, V, 1, 12)
+        oe, og, ol = oc.collate(odb, er, tw.glove_rand.cpu(), perm.cpu())
+        assert torch.equal(E.cpu(), oe) and torch.equal(G.cpu(), og) and torch.equal(L.cpu(), ol)
+
+
+def test_train_cli_end_to_end(tmp_path, capsys):
+    """go.sh recipe on synthetic data, 2 short epochs: runs, learns, checkpoints, tests."""
+    from contrastiveprosthetics_amd import train
+    a = train.build_parser().parse_args(
+        ["--final_epochs=2", "--crossval_size=2", "--batch_size=64", "--crossval_load", "--test", "--no_adabn",
+         "--synthetic", "--data_dir", str(tmp_path / "data"), "--checkpoint_dir", str(tmp_path / "ckpt")])
+    train.main(a)
+    out = capsys.readouterr().out
+    assert "Best combination" in out and "Checkpointing model" in out and "loss,\t\t\tcorrect" in out
+    ck = torch.load(tmp_path / "ckpt" / "contrastive.pt", weights_only=True)
+    assert len(ck) == 68
+    lines = [l for l in out.splitlines() if l.startswith("Epoch")]
+    first, last = lines[0], lines[-1]
+    tl = lambda s: float(s.split("Train loss:")[1].split()[0])
+    assert tl(last) < tl(first) < 3.8                         # class-dependent synthetic signal is learnable
