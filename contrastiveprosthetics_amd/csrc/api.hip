@@ -8,8 +8,11 @@
 #include "../../include/cpnative.h"
 #include "common.cuh"
 #include "gemm_nt.cuh"
+#include "gemm_nt256.cuh"
 #include "gemm_tn.cuh"
+#include "gemm_tn256.cuh"
 #include "kernels_misc.cuh"
+#include "conv_kernels.cuh"
 #include "head.cuh"
 #include "optim.cuh"
 
@@ -120,7 +123,7 @@ struct WS {
     size_t total;
     size_t partials_floats, slabs_floats;
 };
-static const size_t kSlabFloats = (size_t)32 * 512 * 768;
+static const size_t kSlabFloats = (size_t)64 * 512 * 512 + 1024;   // 64 splits of a 512x512 (or 40 of a 512x768) f32 slab
 static const int kHeadBlocksMax = 1024;
 
 static WS carve(int64_t N, int dtype, float dp) {
@@ -211,6 +214,24 @@ static inline int grid_rows(int64_t rows, int rows_per_block, int cap) {
     return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
+// fc-layer NT GEMM dispatch: bf16 runs the 256x256 global_load_lds kernel, f32 (parity path) the
+// 128x128 register-staged one.  FcTile<T>::BM = rows per tile = rows per BN-partial row.
+template <typename T> struct FcTile { static constexpr int BM = 128; };
+template <> struct FcTile<bf16_t> { static constexpr int BM = 256; };
+template <typename T, int EPI>
+static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) return launch_gemm_nt256<EPI>(a, st);
+    else return launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI>(a, st);
+}
+
+// persistent conv strip kernels: blocks per CU allowed by their LDS footprint (bf16 70 KB, f32 116 KB)
+template <typename T>
+static inline int conv_grid(int64_t n_windows) {
+    const int64_t strips = (n_windows + CONV_WPB - 1) / CONV_WPB;
+    const int64_t cap = sizeof(T) == 2 ? 512 : 256;
+    return (int)(strips < cap ? strips : cap);
+}
+
 // fold many partial rows into REDUCE_SLICES rows (parallel) before a single-block finalize
 struct PreReduce {
     const float* partials;
@@ -260,23 +281,24 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const int g = grid_rows(R12, RPP, 2048);
         {
             ProfScope ps(CP_K_CONV1_FWD, st);
-            hipLaunchKernelGGL((conv1_fwd_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, act(0), partials, R12);
-            CKL("conv1_fwd_kernel");
+            // statistics only: r1 is never stored, its consumers recompute it from x (conv_kernels.cuh)
+            hipLaunchKernelGGL((conv1_stats_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, partials, R12);
+            CKL("conv1_stats_kernel");
         }
         if (int e = finalize(0, g, (double)R12)) return e;
     }
     // conv2
     {
-        GemmNTArgs a{};
-        a.A = act(0); a.lda = 64; a.M = R12; a.K = 192;
-        a.W = base + w.wc2_f; a.F = 64;
-        a.C = act(1); a.ldc = 64; a.bias = p->conv2_b; a.relu = 1;
-        a.partials = partials; a.a_scale = stats(0) + 2 * 64; a.a_shift = stats(0) + 3 * 64;
+        ConvArgs ca{};
+        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0);
+        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = act(1); ca.partials = partials; ca.n_windows = N;
+        const int g = conv_grid<T>(N);
         {
             ProfScope ps(CP_K_CONV2_FWD, st);
-            CK((launch_gemm_nt<T, 128, 64, ALOAD_CONV, EPI_FWD>(a, st)));
+            hipLaunchKernelGGL((conv2_strip_kernel<T, 0>), dim3(g), dim3(256), 0, st, ca);
+            CKL("conv2_strip_kernel<fwd>");
         }
-        if (int e = finalize(1, (int)((R12 + 127) / 128), (double)R12)) return e;
+        if (int e = finalize(1, g, (double)R12)) return e;
     }
     // fc1..fc7
     for (int i = 0; i < CP_N_FC; ++i) {
@@ -304,9 +326,9 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         a.partials = partials;
         {
             ProfScope ps(CP_K_FC_FWD, st);
-            CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_FWD>(a, st)));
+            CK((launch_fc_gemm<T, EPI_FWD>(a, st)));
         }
-        if (int e = finalize(L, (int)((N + 127) / 128), (double)N)) return e;
+        if (int e = finalize(L, (int)((N + FcTile<T>::BM - 1) / FcTile<T>::BM), (double)N)) return e;
     }
     // projection 512 -> 16 (weights padded to 32 rows)
     {
@@ -414,7 +436,8 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     float* coef = (float*)(base + w.coef);
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
-    const int tiles_n = (int)((N + 127) / 128);
+    const int tiles_n = (int)((N + FcTile<T>::BM - 1) / FcTile<T>::BM);
+    int conv_dgrad_rows = 0;
     const PreReduce pre{partials, (float*)(base + w.partials2), st};
 
     {
@@ -456,7 +479,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         a.W = base + w.wlast_t; a.F = 512;
         a.C = cur; a.ldc = 512; a.R = act(8); a.ldr = 512; a.partials = partials;
         if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
-        CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_DGRAD>(a, st)));
+        CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
     }
     // ---- fc7 .. fc1 --------------------------------------------------------------------
     for (int L = 8; L >= 2; --L) {
@@ -479,11 +502,19 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         const T* Y = in_drop ? (const T*)(base + w.u[Lp - 5]) : act(Lp);
         const float* s = in_drop ? nullptr : stats(Lp) + 2 * kLayerC[Lp];
         const float* t = in_drop ? nullptr : stats(Lp) + 3 * kLayerC[Lp];
-        GemmTNArgs ta{};
-        ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
         int S;
-        split_rows(N, 32, &S, &ta.rows_per_split);
-        {
+        if constexpr (sizeof(T) == 2) {
+            // 256x256 tiles: 4 (K=512) or 6 (K=768) tiles x ~256/tiles splits = one block per CU
+            GemmTN256Args ta{};
+            ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
+            split_rows(N, K == 512 ? 64 : 40, &S, &ta.rows_per_split);
+            ta.splits = S;
+            ProfScope ps(CP_K_FC_WGRAD, st);
+            CK(launch_gemm_tn256(ta, st));
+        } else {
+            GemmTNArgs ta{};
+            ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
+            split_rows(N, 32, &S, &ta.rows_per_split);
             ProfScope ps(CP_K_FC_WGRAD, st);
             CK((launch_gemm_tn<T, 128, 128, YLOAD_PLAIN>(ta, S, st)));
         }
@@ -500,7 +531,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         if (in_drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
         {
             ProfScope ps(CP_K_FC_DGRAD, st);
-            CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_DGRAD>(a, st)));
+            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
         }
         T* tmp = cur; cur = nxt; nxt = tmp;
     }
@@ -520,38 +551,38 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, pp, nr, 64, g->conv2_b);
             CKL("bn_relu_bwd_kernel(conv2)");
         }
-        GemmTNArgs ta{};
-        ta.X = cur; ta.ldx = 64; ta.Y = act(0); ta.ldy = 64; ta.slabs = slabs; ta.M = R12; ta.P = 64; ta.Q = 192;
-        ta.y_scale = stats(0) + 2 * 64; ta.y_shift = stats(0) + 3 * 64;
-        int S;
-        split_rows(R12, 256, &S, &ta.rows_per_split);
+        ConvArgs ca{};
+        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0); ca.gin = cur; ca.n_windows = N;
         {
             ProfScope ps(CP_K_CONV2_WGRAD, st);
-            CK((launch_gemm_tn<T, 64, 64, YLOAD_CONV>(ta, S, st)));
+            const int64_t strips = (N + CONV_WG_WPB - 1) / CONV_WG_WPB;
+            const int64_t cap = sizeof(T) == 2 ? 768 : 256;      // 3 blocks per CU fit in LDS (44 KB) in bf16
+            const int S = (int)(strips < cap ? strips : cap);
+            ca.partials = slabs;
+            hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, slabs, S, 64, 192, 64, (const float*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2);
-            CKL("reduce_slabs(conv2)");
+            CKL("conv2_wgrad_kernel");
         }
-        GemmNTArgs a{};
-        a.A = cur; a.lda = 64; a.M = R12; a.K = 192;
-        a.W = base + w.wc2_d; a.F = 64;
-        a.C = nxt; a.ldc = 64; a.R = act(0); a.ldr = 64; a.partials = partials;
+        conv_dgrad_rows = conv_grid<T>(N);
+        ca.wc = base + w.wc2_d; ca.out = nxt; ca.partials = partials;
         {
             ProfScope ps(CP_K_CONV2_DGRAD, st);
-            CK((launch_gemm_nt<T, 128, 64, ALOAD_CONV, EPI_DGRAD>(a, st)));
+            hipLaunchKernelGGL((conv2_strip_kernel<T, 1>), dim3(conv_dgrad_rows), dim3(256), 0, st, ca);
+            CKL("conv2_strip_kernel<dgrad>");
         }
     }
     // ---- conv1 -----------------------------------------------------------------------------
     {
         ProfScope ps(CP_K_CONV1_BWD, st);
-        int nr = (int)((R12 + 127) / 128);
+        int nr = conv_dgrad_rows;
         const float* pp = pre(nr, 2 * 64);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, (double)R12, stats(0), coef, g->bn_g[0],
                            g->bn_b[0], 64, 1);
         CKL("bn_bwd_finalize_kernel(conv1)");
         constexpr int RPP = 256 / (64 / D::EPC);
         const int gb = grid_rows(R12, RPP, 2048);
-        hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, act(0), x, coef, partials, R12);
+        hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, x, p->conv1_w, p->conv1_b, coef, partials, R12);
         nr = gb;
         pp = pre(nr, 4 * 64);
         hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, g->conv1_w, g->conv1_b);
@@ -646,13 +677,26 @@ __global__ void to_f32_kernel(const T* __restrict__ in, float* __restrict__ out,
         out[i] = DT<T>::load(in + i);
 }
 
-extern "C" int cp_debug_activation(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer, float* out, void* stream) {
+extern "C" int cp_debug_activation(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,
+                                   int32_t layer, float* out, void* stream) {
     WS w;
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (layer < 0 || layer >= CP_N_BN + 4 || !out) return fail(CP_ERR_ARG, "cp_debug_activation args");
     if (layer >= CP_N_BN && !(cfg->dp_emg > 0.f)) return fail(CP_ERR_ARG, "dropout buffers exist only when dp_emg > 0");
     const int64_t n = cfg->n_windows * (layer < 2 ? 768 : 512);
     unsigned char* base = (unsigned char*)ws;
+    if (layer == 0) {   // conv1's output is never stored: recompute it exactly as its consumers do
+        if (!p || !x) return fail(CP_ERR_ARG, "layer 0 needs params and x");
+        const int64_t rows = cfg->n_windows * 12;
+        if (cfg->dtype == CP_BF16)
+            hipLaunchKernelGGL((conv1_materialize_kernel<bf16_t>), dim3(1024), dim3(256), 0, (hipStream_t)stream, x, p->conv1_w,
+                               p->conv1_b, out, rows);
+        else
+            hipLaunchKernelGGL((conv1_materialize_kernel<float>), dim3(1024), dim3(256), 0, (hipStream_t)stream, x, p->conv1_w,
+                               p->conv1_b, out, rows);
+        CKL("conv1_materialize_kernel");
+        return 0;
+    }
     const size_t off = layer < CP_N_BN ? w.act[layer] : w.u[layer - CP_N_BN];
     if (cfg->dtype == CP_BF16)
         hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(1024), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)(base + off), out, n);
@@ -660,6 +704,41 @@ extern "C" int cp_debug_activation(const cp_config* cfg, void* ws, size_t ws_byt
         hipLaunchKernelGGL((to_f32_kernel<float>), dim3(1024), dim3(256), 0, (hipStream_t)stream, (const float*)(base + off), out, n);
     CKL("to_f32_kernel");
     return 0;
+}
+
+template <typename T>
+static int debug_gemm_t(int kind, int64_t M, int K, int F, const void* A, const void* W, void* C, const float* bias,
+                        const void* R, float* partials, int dbg, hipStream_t st) {
+    if (kind == 2) {
+        int S;
+        if constexpr (sizeof(T) == 2) {
+            GemmTN256Args ta{};
+            ta.X = (const bf16_t*)A; ta.ldx = K; ta.Y = (const bf16_t*)W; ta.ldy = F; ta.slabs = (float*)C; ta.M = M; ta.P = K; ta.Q = F;
+            split_rows(M, F == 512 ? 64 : 40, &S, &ta.rows_per_split);
+            ta.splits = S;
+            CK(launch_gemm_tn256(ta, st));
+        } else {
+            GemmTNArgs ta{};
+            ta.X = A; ta.ldx = K; ta.Y = W; ta.ldy = F; ta.slabs = (float*)C; ta.M = M; ta.P = K; ta.Q = F;
+            split_rows(M, 32, &S, &ta.rows_per_split);
+            CK((launch_gemm_tn<T, 128, 128, YLOAD_PLAIN>(ta, S, st)));
+        }
+        return 0;
+    }
+    GemmNTArgs a{};
+    a.A = A; a.lda = K; a.M = M; a.K = K; a.W = W; a.F = F; a.C = C; a.ldc = F; a.bias = bias; a.relu = 1;
+    a.R = R; a.ldr = F; a.partials = partials; a.dbg = dbg;
+    if (kind == 0) CK((launch_fc_gemm<T, EPI_FWD>(a, st)));
+    else CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
+    return 0;
+}
+
+extern "C" int cp_debug_gemm(int32_t dtype, int32_t kind, int64_t M, int32_t K, int32_t F, const void* A, const void* W,
+                             void* C, const float* bias, const void* R, float* partials, int32_t dbg, void* stream) {
+    if (!A || !W || !C || !partials || M <= 0 || K % 64 || F % 256 || kind < 0 || kind > 2)
+        return fail(CP_ERR_ARG, "cp_debug_gemm args");
+    if (dtype == CP_BF16) return debug_gemm_t<bf16_t>(kind, M, K, F, A, W, C, bias, R, partials, dbg, (hipStream_t)stream);
+    return debug_gemm_t<float>(kind, M, K, F, A, W, C, bias, R, partials, dbg, (hipStream_t)stream);
 }
 
 extern "C" int cp_debug_bn_stats(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer, float* out, void* stream) {

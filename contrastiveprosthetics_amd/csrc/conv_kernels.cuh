@@ -1,0 +1,454 @@
+// Conv front-end (code/models.py:255-261 on (N,1,1,12) input, so only kernel row 1 of each 3x3
+// touches data).  conv1's input is 12 floats per window, so its 768-element output r1 is NEVER
+// stored: every consumer (conv2 forward, conv2 weight gradient, the BN-backward sums of conv2's
+// data gradient, conv1's own backward) recomputes  r1 = round_T(relu(b + sum_tap W[tap] x[w+tap-1]))
+// from x while it stages its LDS image.  That removes one 258 MB write and four 258 MB reads per
+// step at 167,936 windows.
+//
+// conv2 is an implicit GEMM over "strips" of 16 windows: the strip's input is held in LDS as an
+// image of 14 rows per window (zero row, 12 positions, zero row) x 64 channels, so the three taps
+// are the same image read at row offsets 0/1/2 and the zero padding is real zeros.  Blocks are
+// persistent (weights stay in LDS, BN partial sums stay in registers across strips).
+#pragma once
+#include "common.cuh"
+#include "gemm_tn.cuh"
+
+#define CONV_WPB 16                      // windows per strip
+#define CONV_ROWS (CONV_WPB * 12)        // 192 output rows per strip
+#define CONV_IMG_ROWS (CONV_WPB * 14)    // 224 image rows per strip
+
+struct ConvArgs {
+    const float* x;         // [N][12]
+    const float* w1;        // conv_emg.0.weight (64,1,3,3)
+    const float* b1;        // conv_emg.0.bias (64)
+    const float* stats1;    // BN1 [4][64] mean, invstd, scale, shift (nullptr: image holds raw r1)
+    const void* wc;         // conv2 weights in compute dtype [64][192] (k = tap*64 + in-channel)
+    const float* bias2;     // conv_emg.3.bias (forward)
+    const void* gin;        // [N*12][64] T gradient wrt conv2's pre-BN output (dgrad / wgrad)
+    void* out;              // forward: r2, dgrad: g_v1   [N*12][64] T
+    float* partials;        // [grid][2][64] (fwd: sum, sumsq of r2; dgrad: sum g, sum g*r1) / wgrad: slabs [grid][64][192]
+    int64_t n_windows;
+};
+
+template <typename T> struct ConvGeo {
+    using D = DT<T>;
+    static constexpr int EPC = D::EPC;
+    static constexpr int CPR = 64 / EPC;                 // 16-byte chunks per 64-channel row
+    static constexpr int ROWB = 64 * (int)sizeof(T);     // bytes per image row
+    static constexpr int RPP = 256 / CPR;                // rows handled per pass by 256 threads
+    static constexpr int WPITCH = 192 * (int)sizeof(T) + 16;
+    static constexpr int CPITCH = ROWB + 16;
+    __device__ static __forceinline__ int swz(int row) { return sizeof(T) == 2 ? ((row >> 1) & 7) : (row & 15); }
+    __device__ static __forceinline__ int img_off(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
+};
+
+// conv1 for one (window, position) and the EPC channels of one chunk: value exactly as stored
+// activations are rounded (stats, BN-backward sums and conv2's input all see the same number)
+template <typename T>
+__device__ __forceinline__ void conv1_chunk(const float* __restrict__ x, int64_t win, int w, const float (*wt)[3],
+                                            const float* bs, float* out) {
+    using D = DT<T>;
+    // unconditional loads at clamped positions + selects: no divergent branch around a load, so the
+    // loads of several unrolled callers are issued back to back
+    const float* xr = x + win * 12;
+    const float x0 = xr[w];
+    const float xl = xr[w > 0 ? w - 1 : 0];
+    const float xh = xr[w < 11 ? w + 1 : 11];
+    const float xm = w > 0 ? xl : 0.f;
+    const float xp = w < 11 ? xh : 0.f;
+#pragma unroll
+    for (int e = 0; e < D::EPC; ++e) {
+        float y = bs[e];
+        y = fmaf(wt[e][0], xm, y);
+        y = fmaf(wt[e][1], x0, y);
+        y = fmaf(wt[e][2], xp, y);
+        out[e] = D::round(fmaxf(y, 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 forward: BatchNorm2d statistics of r1 only (nothing is stored)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ partials,
+                                                          int64_t rows) {
+    using G = ConvGeo<T>;
+    constexpr int EPC = G::EPC, CPR = G::CPR, RPP = G::RPP;
+    __shared__ float red[2][RPP][64];
+    const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
+    float wt[EPC][3], bs[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wt[e][k] = w[(cc * EPC + e) * 9 + 3 + k];
+        bs[e] = bias[cc * EPC + e];
+        s1[e] = s2[e] = 0.f;
+    }
+    for (int64_t m = (int64_t)blockIdx.x * RPP + rr; m < rows; m += (int64_t)gridDim.x * RPP) {
+        float v[EPC];
+        conv1_chunk<T>(x, m / 12, (int)(m % 12), wt, bs, v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { red[0][rr][cc * EPC + e] = s1[e]; red[1][rr][cc * EPC + e] = s2[e]; }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        float s = 0.f;
+        for (int q = 0; q < RPP; ++q) s += red[which][q][c];
+        partials[((int64_t)blockIdx.x * 2 + which) * 64 + c] = s;
+    }
+}
+
+// debug/test only: materialise r1 [N*12][64] as f32
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_materialize_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                int64_t rows) {
+    using G = ConvGeo<T>;
+    constexpr int EPC = G::EPC, CPR = G::CPR, RPP = G::RPP;
+    const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
+    float wt[EPC][3], bs[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wt[e][k] = w[(cc * EPC + e) * 9 + 3 + k];
+        bs[e] = bias[cc * EPC + e];
+    }
+    for (int64_t m = (int64_t)blockIdx.x * RPP + rr; m < rows; m += (int64_t)gridDim.x * RPP) {
+        float v[EPC];
+        conv1_chunk<T>(x, m / 12, (int)(m % 12), wt, bs, v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) out[m * 64 + cc * EPC + e] = v[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv2 forward (MODE 0) and conv2 data gradient (MODE 1), persistent strip kernel.
+//   MODE 0: image = BN1(r1) recomputed from x;  out = relu(conv + bias2);  sums: out, out^2
+//   MODE 1: image = g_y2 strip from HBM;        out = g_v1;                sums: g, g * r1(recomputed)
+// 4 waves: wave w computes feature tile (w&1) x sample tiles 3*(w>>1)+{0,1,2} of the 192 x 64 strip.
+// ------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
+    using D = DT<T>;
+    using G = ConvGeo<T>;
+    constexpr int EPC = G::EPC, CPR = G::CPR, ROWB = G::ROWB, RPP = G::RPP, WPITCH = G::WPITCH, CPITCH = G::CPITCH;
+    constexpr int KSTEP = D::KSTEP, KS_PER_TAP = 64 / KSTEP, NKS = 3 * KS_PER_TAP;
+    constexpr int IMG_BYTES = CONV_IMG_ROWS * ROWB, C_BYTES = CONV_ROWS * CPITCH;
+    constexpr int REGION = IMG_BYTES > C_BYTES ? IMG_BYTES : C_BYTES;
+    constexpr int W_BYTES = 64 * WPITCH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[REGION + W_BYTES + 2 * RPP * 64 * 4];
+    unsigned char* img = smem;
+    unsigned char* Cs = smem;                      // aliases the image once the MFMAs are done
+    unsigned char* Wl = smem + REGION;
+    float* red = (float*)(smem + REGION + W_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int cc = tid % CPR, rr = tid / CPR;
+    const int ft = wave & 1, st0 = 3 * (wave >> 1);
+    const int64_t nstrips = (a.n_windows + CONV_WPB - 1) / CONV_WPB;
+    const int64_t total_rows = a.n_windows * 12;
+
+    // conv2 weights -> LDS (padded pitch: 16 rows x one chunk land on 16 distinct 16-byte slots)
+    for (int i = tid; i < 64 * (192 / EPC); i += 256) {
+        const int row = i / (192 / EPC), ch = i % (192 / EPC);
+        *(uint4*)(Wl + row * WPITCH + ch * 16) = *(const uint4*)((const T*)a.wc + row * 192 + ch * EPC);
+    }
+    // conv1 parameters of this thread's channel chunk (image build in MODE 0, r1 recompute in MODE 1)
+    float wt[EPC][3], bs[EPC], sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = cc * EPC + e;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wt[e][k] = a.w1[c * 9 + 3 + k];
+        bs[e] = a.b1[c];
+        sc[e] = (MODE == 0 && a.stats1) ? a.stats1[2 * 64 + c] : 1.f;
+        sh[e] = (MODE == 0 && a.stats1) ? a.stats1[3 * 64 + c] : 0.f;
+    }
+    float b2v[4][4];                               // conv2 bias of this lane's 16 output features
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b2v[q][e] = (MODE == 0) ? a.bias2[ft * 32 + 8 * q + 4 * h + e] : 0.f;
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+
+    for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int64_t win0 = strip * CONV_WPB;
+        // ---- stage the image: 16 windows x 14 rows x 64 channels ------------------------------
+        // (fully unrolled: the CONV_IMG_ROWS / RPP independent global loads are issued together)
+        {
+            constexpr int NIT = CONV_IMG_ROWS / RPP;
+            uint4 v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int ir = rr + it * RPP;
+                const int nl = ir / 14, wp = ir % 14;
+                const int64_t win = win0 + nl;
+                const bool ok = wp >= 1 && wp <= 12 && win < a.n_windows;
+                const int64_t winc = ok ? win : 0;                 // clamped: the load itself is unconditional
+                const int wpos = ok ? wp - 1 : 0;
+                if constexpr (MODE == 0) {
+                    float t[EPC];
+                    conv1_chunk<T>(a.x, winc, wpos, wt, bs, t);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
+                    v[it] = D::pack(t);
+                } else {
+                    v[it] = *(const uint4*)((const T*)a.gin + (winc * 12 + wpos) * 64 + cc * EPC);
+                }
+                if (!ok) v[it] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) *(uint4*)(img + G::img_off(rr + it * RPP, cc)) = v[it];
+        }
+        __syncthreads();
+        // ---- implicit GEMM: out[m][f] = sum_tap sum_c image[row(m)+tap][c] * W[f][tap*64+c] ----
+        f32x16 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+        int ir0[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ml = (st0 + j) * 32 + r;
+            ir0[j] = (ml / 12) * 14 + (ml % 12);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int tap = ks / KS_PER_TAP, chunk = (ks % KS_PER_TAP) * 2 + h;
+            const uint4 fw = *(const uint4*)(Wl + (ft * 32 + r) * WPITCH + ks * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint4 fs = *(const uint4*)(img + G::img_off(ir0[j] + tap, chunk));
+                mma_chunk<T>(fw, fs, acc[j]);
+            }
+        }
+        __syncthreads();                           // image dead: the region becomes the output tile
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int srow = (st0 + j) * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int fl = ft * 32 + 8 * q + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xv = acc[j][4 * q + e];
+                    if constexpr (MODE == 0) xv = fmaxf(xv + b2v[q][e], 0.f);
+                    v[e] = xv;
+                }
+                unsigned char* dst = Cs + srow * CPITCH + fl * (int)sizeof(T);
+                if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        // ---- store-out: 16-byte row segments + BatchNorm partial sums ----------------------------
+#pragma unroll
+        for (int p = 0; p < CONV_ROWS / RPP; ++p) {
+            const int row = rr + p * RPP;
+            const int64_t m = win0 * 12 + row;
+            const bool ok = m < total_rows;
+            const int64_t mc = ok ? m : 0;                      // loads unconditional, only the store is guarded
+            const uint4 c = *(const uint4*)(Cs + row * CPITCH + cc * 16);
+            float v[EPC];
+            D::unpack(c, v);
+            const float keep = ok ? 1.f : 0.f;
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1[e] = fmaf(keep, v[e], s1[e]); s2[e] = fmaf(keep * v[e], v[e], s2[e]); }
+            } else {
+                float r1[EPC];
+                conv1_chunk<T>(a.x, mc / 12, (int)(mc % 12), wt, bs, r1);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1[e] = fmaf(keep, v[e], s1[e]); s2[e] = fmaf(keep * v[e], r1[e], s2[e]); }
+            }
+            if (ok) *(uint4*)((T*)a.out + m * 64 + cc * EPC) = c;
+        }
+        __syncthreads();                           // output tile dead before the next image is staged
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { red[(0 * RPP + rr) * 64 + cc * EPC + e] = s1[e]; red[(1 * RPP + rr) * 64 + cc * EPC + e] = s2[e]; }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        float s = 0.f;
+        for (int q = 0; q < RPP; ++q) s += red[(which * RPP + q) * 64 + c];
+        a.partials[((int64_t)blockIdx.x * 2 + which) * 64 + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv2 weight gradient, persistent:  dW[o][tap*64+i] = sum_m g_y2[m][o] * u1[m + tap - 1][i]
+// Both operands are held as padded images (zero row, 12 positions, zero row per window) with one
+// extra zero guard row at each end, so the tap is a constant row shift of the X image and the
+// reduction simply runs over all image rows of the strip (8 windows).  4 waves: wave w owns
+// output-channel tile (w&1), in-channel tile (w>>1) and all three taps of the 64 x 192 result, kept
+// in registers across strips; one f32 slab per block at the end (reduce_slabs_kernel mode 2 sums them).
+// ------------------------------------------------------------------------------------------
+#define CONV_WG_WPB 8                                  // windows per strip of the weight-gradient kernel
+#define CONV_WG_IMG (CONV_WG_WPB * 14)                 // 112 image rows (a multiple of the 16-row k-step)
+template <typename T>
+__global__ __launch_bounds__(256) void conv2_wgrad_kernel(ConvArgs a) {
+    using D = DT<T>;
+    using G = ConvGeo<T>;
+    constexpr int EPC = G::EPC, CPR = G::CPR, RPP = G::RPP, KSTEP = D::KSTEP;
+    constexpr int PITCH = TNPitch<T, 64>::value;              // row pitch that keeps the transposed reads conflict-free
+    constexpr int ROWS = CONV_WG_IMG + 2;                     // guard row before and after
+    constexpr int NIT = (CONV_WG_IMG + RPP - 1) / RPP;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ROWS * PITCH];
+    unsigned char* Xi = smem;                                 // g_y2 image
+    unsigned char* Yi = smem + ROWS * PITCH;                  // u1 image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cc = tid % CPR, rr = tid / CPR;
+    const int ot = wave & 1, it = wave >> 1;                  // this wave: out-channel tile, in-channel tile, all 3 taps
+    const int64_t nstrips = (a.n_windows + CONV_WG_WPB - 1) / CONV_WG_WPB;
+
+    float wt[EPC][3], bs[EPC], sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = cc * EPC + e;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wt[e][k] = a.w1[c * 9 + 3 + k];
+        bs[e] = a.b1[c];
+        sc[e] = a.stats1[2 * 64 + c];
+        sh[e] = a.stats1[3 * 64 + c];
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+    // guard rows stay zero for the whole kernel
+    if (rr == 0) {
+        *(uint4*)(Xi + 0 * PITCH + cc * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(Xi + (ROWS - 1) * PITCH + cc * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(Yi + 0 * PITCH + cc * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(Yi + (ROWS - 1) * PITCH + cc * 16) = make_uint4(0, 0, 0, 0);
+    }
+    for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int64_t win0 = strip * CONV_WG_WPB;
+        {
+            uint4 xv[NIT], yv[NIT];
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {                   // all gradient loads of the strip are issued together
+                const int ir = rr + q * RPP;
+                const int nl = ir / 14, wp = ir % 14;
+                const int64_t win = win0 + nl;
+                const bool ok = ir < CONV_WG_IMG && wp >= 1 && wp <= 12 && win < a.n_windows;
+                const int64_t winc = ok ? win : 0;                 // clamped: loads are unconditional
+                const int wpos = ok ? wp - 1 : 0;
+                xv[q] = *(const uint4*)((const T*)a.gin + (winc * 12 + wpos) * 64 + cc * EPC);
+                float t[EPC];
+                conv1_chunk<T>(a.x, winc, wpos, wt, bs, t);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
+                yv[q] = D::pack(t);
+                if (!ok) { xv[q] = make_uint4(0, 0, 0, 0); yv[q] = make_uint4(0, 0, 0, 0); }
+            }
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const int ir = rr + q * RPP;
+                if (ir < CONV_WG_IMG) {
+                    *(uint4*)(Xi + (ir + 1) * PITCH + cc * 16) = xv[q];
+                    *(uint4*)(Yi + (ir + 1) * PITCH + cc * 16) = yv[q];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < CONV_WG_IMG; k0 += KSTEP) {
+            // image row j lives at LDS row j+1; the X row paired with Y image row j under tap t is image row j - t + 1
+            uint4 fy;
+            if constexpr (sizeof(T) == 2) fy = tn_frag_bf16<PITCH>(Yi, k0 + 1, it * 32, lane);
+            else fy = tn_frag_f32<PITCH>(Yi, k0 + 1, it * 32, lane);
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                uint4 fx;
+                if constexpr (sizeof(T) == 2) fx = tn_frag_bf16<PITCH>(Xi, k0 + 2 - tap, ot * 32, lane);
+                else fx = tn_frag_f32<PITCH>(Xi, k0 + 2 - tap, ot * 32, lane);
+                mma_chunk<T>(fx, fy, acc[tap]);
+            }
+        }
+        __syncthreads();
+    }
+    float* slab = a.partials + (int64_t)blockIdx.x * 64 * 192;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        const int q = tap * 64 + it * 32 + r;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int p = ot * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            slab[p * 192 + q] = acc[tap][g];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 backward: BN1+ReLU backward fused with conv1's dW/db; r1 recomputed, nothing else read
+// but g_v1.  partials[block][4][64]: dW tap0..2, db.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const T* __restrict__ g, const float* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ coef, float* __restrict__ partials,
+                                                        int64_t rows) {
+    using Gm = ConvGeo<T>;
+    using D = DT<T>;
+    constexpr int EPC = Gm::EPC, CPR = Gm::CPR, RPP = Gm::RPP, C = 64;
+    __shared__ float red[4][RPP][64];
+    const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
+    float wt[EPC][3], bs[EPC], ca[EPC], cb[EPC], cz[EPC], acc[4][EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = cc * EPC + e;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wt[e][k] = w[c * 9 + 3 + k];
+        bs[e] = bias[c];
+        ca[e] = coef[c];
+        cb[e] = coef[C + c];
+        cz[e] = coef[2 * C + c];
+        acc[0][e] = acc[1][e] = acc[2][e] = acc[3][e] = 0.f;
+    }
+    for (int64_t m = (int64_t)blockIdx.x * RPP + rr; m < rows; m += (int64_t)gridDim.x * RPP) {
+        const int wpos = (int)(m % 12);
+        const float* xr = x + (m / 12) * 12;
+        const float x0 = xr[wpos];
+        const float xm = wpos > 0 ? xr[wpos - 1] : 0.f;
+        const float xp = wpos < 11 ? xr[wpos + 1] : 0.f;
+        float gv[EPC], rv[EPC];
+        D::unpack(*(const uint4*)(g + m * C + cc * EPC), gv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float y = bs[e];
+            y = fmaf(wt[e][0], xm, y);
+            y = fmaf(wt[e][1], x0, y);
+            y = fmaf(wt[e][2], xp, y);
+            rv[e] = D::round(fmaxf(y, 0.f));
+            const float gy = rv[e] > 0.f ? fmaf(ca[e], gv[e], fmaf(cb[e], rv[e], cz[e])) : 0.f;
+            acc[0][e] = fmaf(gy, xm, acc[0][e]);
+            acc[1][e] = fmaf(gy, x0, acc[1][e]);
+            acc[2][e] = fmaf(gy, xp, acc[2][e]);
+            acc[3][e] += gy;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[k][rr][cc * EPC + e] = acc[k][e];
+    __syncthreads();
+    {
+        const int k = tid >> 6, c = tid & 63;
+        float s = 0.f;
+        for (int q = 0; q < RPP; ++q) s += red[k][q][c];
+        partials[((int64_t)blockIdx.x * 4 + k) * 64 + c] = s;
+    }
+}

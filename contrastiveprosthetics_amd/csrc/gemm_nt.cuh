@@ -30,6 +30,7 @@ struct GemmNTArgs {
     int K, F;
     int relu;            // EPI_FWD: apply ReLU
     int f_valid;         // EPI_PLAIN_F32: store only features < f_valid
+    int dbg;             // ablation (tools/gemm_bench.py only): 1 skip MFMA, 2 skip epilogue, 4 skip staging loads
     // dropout on the gradient (EPI_DGRAD); thresh == 0 -> none
     uint32_t dp_thresh, dp_key;
     float dp_inv_keep;

@@ -1,0 +1,260 @@
+// bf16 NT GEMM for the fc layers at full batch: 256 x 256 output tile, 8 wavefronts (2 sample
+// halves x 4 feature quarters, each wave 128 samples x 64 features = 4 x 2 MFMA 32x32 tiles,
+// 128 accumulator registers), K-step 64, operands staged HBM -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write), two LDS buffers.
+//
+// LDS image = the 128-byte-row tile of common.cuh (lds_tile_off): a global_load_lds wave
+// instruction writes 1 KiB = 8 rows lane-linearly, so the XOR swizzle is applied to the per-lane
+// SOURCE chunk (lane l of row group g fills physical chunk l&7 of row 8g + (l>>3) with logical chunk
+// (l&7) ^ ((row>>1)&7)) and again on the ds_read side (guide rule 21: both sides or neither).
+//
+// Block -> tile map: the F/256 feature tiles of one 256-row sample tile run back to back on ONE
+// XCD (blocks b and b+8 share an XCD under round-robin dispatch), so the second read of the A tile
+// hits that XCD's L2 instead of HBM.  A speed choice only: correctness does not depend on placement.
+//
+// Epilogues as in gemm_nt.cuh (EPI_FWD: bias + ReLU + BN sums; EPI_DGRAD: dropout + BN-backward sums).
+#pragma once
+#include "common.cuh"
+#include "gemm_nt.cuh"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// One LDS-DMA wave instruction (1 KiB): LDS[lds_dst + 16*lane] = *(16 bytes at gsrc), issued from
+// inline asm so that hipcc does NOT track it: with the builtin the compiler waits vmcnt(0) before
+// the next ds_read of the same __shared__ array, which serialises the next tile's loads with the
+// current tile's MFMAs.  M0 (the LDS base) is compiler-reserved, so it is saved, set and restored
+// inside the one statement (guide 5.7).  Completion is ordered by the explicit vmcnt waits below.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_uniform)
+                 : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
+    using T = bf16_t;
+    using D = DT<T>;
+    constexpr int BM = 256, BN = 256, BK = 64, EPC = 8;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;            // 32 KiB each
+    constexpr int STAGE = A_BYTES + W_BYTES;
+    constexpr int C_PITCH = BN * 2 + 16;
+    constexpr int C_BYTES = BM * C_PITCH;                            // 135,168
+    constexpr int RED_BYTES = 2 * 8 * BN * 4;                        // 16 KiB
+    constexpr int LDS_BYTES = (2 * STAGE > C_BYTES + RED_BYTES) ? 2 * STAGE : (C_BYTES + RED_BYTES);
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_f = a.F / BN;
+    const int64_t tiles_m = (a.M + BM - 1) / BM;
+    // bid = xcd + 8 * ((tile_m / 8) * tiles_f + tile_f),  tile_m = 8 * q + xcd
+    const int xcd = blockIdx.x & 7;
+    const int64_t j = blockIdx.x >> 3;
+    const int tile_f = (int)(j % tiles_f);
+    const int64_t tile_m = (j / tiles_f) * 8 + xcd;
+    if (tile_m >= tiles_m) return;
+    const int64_t m0 = tile_m * BM;
+    const int f0 = tile_f * BN;
+    const int ws = wave >> 2, wf = wave & 3;
+
+    const T* __restrict__ Ag = (const T*)a.A;
+    const T* __restrict__ Wg = (const T*)a.W;
+
+    // per-lane source coordinates of the 4 + 4 row groups this wave stages per K-step
+    const int lrow = lane >> 3, pch = lane & 7;
+    const T* asrc[4];
+    const T* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave + 8 * i) * 8 + lrow;                   // tile row 0..255
+        const int lch = pch ^ ((row >> 1) & 7);
+        int64_t m = m0 + row;
+        if (m >= a.M) m = a.M - 1;                                   // clamp: such rows are never stored
+        asrc[i] = Ag + m * a.lda + lch * EPC;
+        wsrc[i] = Wg + (int64_t)(f0 + row) * a.K + lch * EPC;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage = [&](int buf, int kt) {
+        const uint32_t As = lds0 + buf * STAGE;
+        const uint32_t Ws = As + A_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rg = wave_u + 8 * i;
+            glds16(asrc[i] + k0, As + rg * 1024);
+            glds16(wsrc[i] + k0, Ws + rg * 1024);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][jj][g] = 0.f;
+
+    const int nk = a.K / BK;
+    const bool do_load = !(a.dbg & 4), do_mma = !(a.dbg & 1);
+    if (do_load) stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk && do_load) stage((kt + 1) & 1, kt + 1);
+        const unsigned char* As = smem + (kt & 1) * STAGE;
+        const unsigned char* Ws = As + A_BYTES;
+        if (do_mma) {
+            // fragments of sub-step ks+1 are read while the 8 MFMAs of sub-step ks run
+            uint4 fw[2][2], fs[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fw[0][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, h));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fs[0][jj] = *(const uint4*)(As + lds_tile_off(ws * 128 + jj * 32 + r, h));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        fw[nxt][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, 2 * (ks + 1) + h));
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        fs[nxt][jj] = *(const uint4*)(As + lds_tile_off(ws * 128 + jj * 32 + r, 2 * (ks + 1) + h));
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) mma_chunk<T>(fw[cur][i], fs[cur][jj], acc[i][jj]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    if (a.dbg & 2) {       // timing-only build of the main loop: keep the accumulators alive, store nothing
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) s += acc[i][jj][g];
+        if (s == 12345.678f) a.partials[0] = s;
+        return;
+    }
+    // ---- epilogue: accumulators -> bf16 tile in LDS -> 16-byte row segments to HBM ------------
+    unsigned char* Cs = smem;
+    float* red = (float*)(smem + C_BYTES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int srow = ws * 128 + jj * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int fl = wf * 64 + i * 32 + 8 * q + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][jj][4 * q + e];
+                    if constexpr (EPI == EPI_FWD) {
+                        x += a.bias[f0 + fl + e];
+                        if (a.relu) x = fmaxf(x, 0.f);
+                    }
+                    v[e] = x;
+                }
+                *(uint2*)(Cs + srow * C_PITCH + fl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            }
+        }
+    __syncthreads();
+    constexpr int CPR = BN / EPC;          // 32 chunks per row
+    constexpr int RPP = 512 / CPR;         // 16 rows per pass
+    const int cc = tid % CPR, rr = tid / CPR;
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    T* Cg = (T*)a.C;
+    const T* Rg = (const T*)a.R;
+    // the saved-activation chunks of all 16 passes are independent loads: issue them together (the
+    // accumulators are dead here, registers are plentiful) instead of one dependent load per pass
+    uint4 rpre[BM / RPP];
+    if constexpr (EPI == EPI_DGRAD) {
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p) {
+            int64_t m = m0 + rr + p * RPP;
+            if (m >= a.M) m = a.M - 1;
+            rpre[p] = *(const uint4*)(Rg + m * a.ldr + f0 + cc * EPC);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+        const int row = rr + p * RPP;
+        const int64_t m = m0 + row;
+        if (m < a.M) {
+            uint4 c = *(const uint4*)(Cs + row * C_PITCH + cc * 16);
+            float v[EPC];
+            D::unpack(c, v);
+            const int f = f0 + cc * EPC;
+            if constexpr (EPI == EPI_FWD) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+            } else {
+                float rv[EPC];
+                const uint4 rc = rpre[p];
+                D::unpack(rc, rv);
+                if (a.dp_thresh != 0) {
+#pragma unroll
+                    for (int e = 0; e < EPC; e += 2) {
+                        const uint32_t pr = dropout_pair(a.dp_key, (uint32_t)m, (uint32_t)a.ldc, (uint32_t)(f + e));
+                        v[e] *= dropout_scale(pr, 0, a.dp_thresh, a.dp_inv_keep);
+                        v[e + 1] *= dropout_scale(pr, 1, a.dp_thresh, a.dp_inv_keep);
+                    }
+                    c = D::pack(v);
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float g = D::round(v[e]);
+                    s1[e] += g;
+                    s2[e] = fmaf(g, rv[e], s2[e]);
+                }
+            }
+            *(uint4*)(Cg + m * a.ldc + f) = c;
+        }
+    }
+    // lanes l and l+32 of a wave own the same 8 columns: combine, then one row of sums per wave
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        s1[e] += __shfl_xor(s1[e], 32, 64);
+        s2[e] += __shfl_xor(s2[e], 32, 64);
+    }
+    if (lane < 32) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            red[(0 * 8 + wave) * BN + cc * EPC + e] = s1[e];
+            red[(1 * 8 + wave) * BN + cc * EPC + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    {
+        const int which = tid / BN, col = tid % BN;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[(which * 8 + q) * BN + col];
+        a.partials[(tile_m * 2 + which) * a.F + f0 + col] = s;
+    }
+}
+
+template <int EPI>
+static inline hipError_t launch_gemm_nt256(const GemmNTArgs& a, hipStream_t st) {
+    const int64_t tiles_m = (a.M + 255) / 256;
+    const int64_t groups = (tiles_m + 7) / 8;
+    const int64_t blocks = groups * 8 * (a.F / 256);
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+    return hipGetLastError();
+}

@@ -32,61 +32,6 @@ __global__ void gather_groups_kernel(const float* __restrict__ table, const int6
 }
 
 // ------------------------------------------------------------------------------------
-// conv1 forward (code/models.py:255-257 restated for H=1: only kernel row 1 touches data)
-//   r1[m][c] = relu(b[c] + sum_tap W[c][tap] * x[window][w + tap - 1]),  m = window*12 + w
-// plus per-block per-channel sums of r1 and r1^2 for BatchNorm2d.
-// ------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, T* __restrict__ out,
-                                                        float* __restrict__ partials, int64_t rows) {
-    using D = DT<T>;
-    constexpr int EPC = D::EPC, CPR = 64 / EPC, RPP = 256 / CPR;
-    __shared__ float red[2][RPP][64];
-    const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
-    float wt[EPC][3], bs[EPC], s1[EPC], s2[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        const int c = cc * EPC + e;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) wt[e][k] = w[c * 9 + 3 + k];          // (64,1,3,3): row 1
-        bs[e] = bias[c];
-        s1[e] = s2[e] = 0.f;
-    }
-    for (int64_t m = (int64_t)blockIdx.x * RPP + rr; m < rows; m += (int64_t)gridDim.x * RPP) {
-        const int wpos = (int)(m % 12);
-        const float x0 = x[m];
-        const float xm = wpos > 0 ? x[m - 1] : 0.f;
-        const float xp = wpos < 11 ? x[m + 1] : 0.f;
-        float v[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            float y = bs[e];
-            y = fmaf(wt[e][0], xm, y);
-            y = fmaf(wt[e][1], x0, y);
-            y = fmaf(wt[e][2], xp, y);
-            y = D::round(fmaxf(y, 0.f));
-            v[e] = y;
-            s1[e] += y;
-            s2[e] = fmaf(y, y, s2[e]);
-        }
-        *(uint4*)(out + m * 64 + cc * EPC) = D::pack(v);
-    }
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        red[0][rr][cc * EPC + e] = s1[e];
-        red[1][rr][cc * EPC + e] = s2[e];
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const int which = tid >> 6, c = tid & 63;
-        float s = 0.f;
-        for (int q = 0; q < RPP; ++q) s += red[which][q][c];
-        partials[((int64_t)blockIdx.x * 2 + which) * 64 + c] = s;
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // BatchNorm statistics -> affine (train: batch stats, biased variance, eps 1e-5; running
 // stats updated with momentum and the unbiased variance, as nn.BatchNorm does).
 // partials: [nrows][2][C] (sum, sum of squares).  use_running: eval with stock BN.
@@ -357,55 +302,6 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partials, int n
     out[c] = (float)s;
 }
 
-// ------------------------------------------------------------------------------------
-// conv1 backward: the BN+ReLU backward of layer 1 fused with the weight/bias gradient
-// (conv1 needs no data gradient).  partials[block][4][64]: dW tap0..2, db.
-// ------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void conv1_bwd_kernel(const T* __restrict__ g, const T* __restrict__ r,
-                                                        const float* __restrict__ x, const float* __restrict__ coef,
-                                                        float* __restrict__ partials, int64_t rows) {
-    using D = DT<T>;
-    constexpr int EPC = D::EPC, CPR = 64 / EPC, RPP = 256 / CPR, C = 64;
-    __shared__ float red[4][RPP][64];
-    const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
-    float ca[EPC], cb[EPC], cz[EPC], acc[4][EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        ca[e] = coef[cc * EPC + e];
-        cb[e] = coef[C + cc * EPC + e];
-        cz[e] = coef[2 * C + cc * EPC + e];
-        acc[0][e] = acc[1][e] = acc[2][e] = acc[3][e] = 0.f;
-    }
-    for (int64_t m = (int64_t)blockIdx.x * RPP + rr; m < rows; m += (int64_t)gridDim.x * RPP) {
-        const int wpos = (int)(m % 12);
-        const float x0 = x[m];
-        const float xm = wpos > 0 ? x[m - 1] : 0.f;
-        const float xp = wpos < 11 ? x[m + 1] : 0.f;
-        float gv[EPC], rv[EPC];
-        D::unpack(*(const uint4*)(g + m * C + cc * EPC), gv);
-        D::unpack(*(const uint4*)(r + m * C + cc * EPC), rv);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float y = rv[e] > 0.f ? fmaf(ca[e], gv[e], fmaf(cb[e], rv[e], cz[e])) : 0.f;
-            acc[0][e] = fmaf(y, xm, acc[0][e]);
-            acc[1][e] = fmaf(y, x0, acc[1][e]);
-            acc[2][e] = fmaf(y, xp, acc[2][e]);
-            acc[3][e] += y;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) red[k][rr][cc * EPC + e] = acc[k][e];
-    __syncthreads();
-    {
-        const int k = tid >> 6, c = tid & 63;
-        float s = 0.f;
-        for (int q = 0; q < RPP; ++q) s += red[k][q][c];
-        partials[((int64_t)blockIdx.x * 4 + k) * 64 + c] = s;
-    }
-}
 // dW1[c][0][1][tap] and db1[c] from the partials; the other kernel rows get zero data gradient.
 __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ partials, int nrows, float* __restrict__ dW,
                                           float* __restrict__ db) {

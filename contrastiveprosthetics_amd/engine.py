@@ -214,6 +214,7 @@ class Engine:
         if training and not self.adabn:
             self.num_batches_tracked += 1          # host counter; materialised by running_state()
         self._last = (n, training)
+        self._last_x = x
         return z
 
     def running_state(self) -> "OrderedDict[str, torch.Tensor]":
@@ -288,8 +289,8 @@ class Engine:
         out = torch.empty(n, C_, dtype=torch.float32, device=self.device)
         cfg = self._cfg(n, training)
         ws, nb = self._ws_args(n)
-        _lib.check(self.lib.cp_debug_activation(C.byref(cfg), ws, nb, layer, out.data_ptr(), self._stream()),
-                   "cp_debug_activation")
+        _lib.check(self.lib.cp_debug_activation(C.byref(cfg), C.byref(self._p), self._last_x.data_ptr(), ws, nb, layer,
+                                                out.data_ptr(), self._stream()), "cp_debug_activation")
         return out
 
     def debug_bn_stats(self, layer: int) -> torch.Tensor:

@@ -154,9 +154,20 @@ int cp_profile_summary(int32_t kind, double* total_ms, int64_t* count);
 
 /* debug/test access: copy saved activation `layer` (0..8 = post-ReLU pre-BN output of conv1,
  * conv2, fc1..fc7; rows x C in the internal layout, conv layers position-major [w][c]; 9..12 =
- * dropout(BN(.)) of fc4..fc7, present only when dp_emg > 0 and the forward ran in training) to f32. */
-int cp_debug_activation(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer,
-                        float* out, void* stream);
+ * dropout(BN(.)) of fc4..fc7, present only when dp_emg > 0 and the forward ran in training) to f32.
+ * Layer 0 (conv1) is never stored by the forward pass -- its consumers recompute it from x -- so it
+ * is recomputed here the same way from `p` and `x` (both may be NULL for the other layers). */
+int cp_debug_activation(const cp_config* cfg, const cp_params* p, const float* x, void* ws,
+                        size_t ws_bytes, int32_t layer, float* out, void* stream);
+/* micro-benchmark access (tools/gemm_bench.py): one fc-layer GEMM launch on caller buffers.
+ * kind 0: forward   C[M][F] = relu(A[M][K] W[F][K]^T + bias), column sums -> partials
+ * kind 1: data grad C[M][F] = A[M][K] W[F][K]^T, sums against R[M][F] -> partials
+ * kind 2: weight grad slabs[S][P][Q] = sum_m X[m][P] Y[m][Q]   (A = X, W = Y, K = P, F = Q)
+ * dbg: ablation bits of the bf16 kernels (1 skip MFMA, 2 skip epilogue, 4 skip staging loads). */
+int cp_debug_gemm(int32_t dtype, int32_t kind, int64_t M, int32_t K, int32_t F, const void* A,
+                  const void* W, void* C, const float* bias, const void* R, float* partials,
+                  int32_t dbg, void* stream);
+
 /* BN statistics of `layer` as computed by the last forward: out[4][C] = mean, invstd, scale, shift */
 int cp_debug_bn_stats(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer, float* out,
                       void* stream);
