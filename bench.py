@@ -188,11 +188,21 @@ def main():
         gbs = byts / avg_s / 1e9
         tfl = flops / avg_s / 1e12
         mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
+        # HBM bytes per launch from the committed PMC profile of this same command (tools/parse_profile.py,
+        # separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction); null if not profiled
+        traffic = None
+        kname = {"fc_fwd": "gemm_nt256_kernel<0>", "fc_dgrad": "gemm_nt256_kernel<1>", "fc_wgrad": "gemm_tn256_kernel"}[dom]
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if args.dtype == "bf16" and B == 4096 and os.path.exists(tpath):
+            for k, v in json.load(open(tpath))["kernels"].items():
+                if kname in k:
+                    traffic = v["hbm_bytes_per_launch"]
         bound = "hbm" if byts / (HBM_PEAK_GBS * 1e9) >= flops / (mfma_peak * 1e12) else "mfma"
         roof = dict(bound=bound, kernel=dom, launches=launches, avg_us=avg_s * 1e6,
                     achieved=gbs if bound == "hbm" else tfl, peak=HBM_PEAK_GBS if bound == "hbm" else mfma_peak,
                     unit="GB/s" if bound == "hbm" else "TFLOP/s",
-                    frac=(gbs / HBM_PEAK_GBS) if bound == "hbm" else (tfl / mfma_peak), traffic=None,
+                    frac=(gbs / HBM_PEAK_GBS) if bound == "hbm" else (tfl / mfma_peak), traffic=traffic,
+                    algorithmic_bytes=byts,
                     mfma_tflops=tfl, mfma_frac=tfl / mfma_peak, hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
                     gemm_ms_per_step={k: prof[k][0] / args.steps for k in gemm_kinds if k in prof})
         rec = dict(metric="sEMG windows/sec contrastive step, 12-ch Ninapro", value=world * N * args.steps / elapsed,

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/cpnative.h"
 #include "common.cuh"
@@ -214,10 +215,12 @@ static inline int grid_rows(int64_t rows, int rows_per_block, int cap) {
     return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
-// fc-layer NT GEMM dispatch: bf16 runs the 256x256 global_load_lds kernel, f32 (parity path) the
-// 128x128 register-staged one.  FcTile<T>::BM = rows per tile = rows per BN-partial row.
-template <typename T> struct FcTile { static constexpr int BM = 128; };
-template <> struct FcTile<bf16_t> { static constexpr int BM = 256; };
+// fc-layer NT GEMM dispatch: bf16 runs the 256x256 LDS-DMA kernel (one 8-wave block per CU), f32
+// (parity path) the 128x128 register-staged one.  fc_bm<T>() = rows per tile = rows per BN-partial row.
+// (A 128x256-tile variant with two 4-wave blocks per CU was measured and dropped: 201 vs 148 us per
+//  512x512 layer at 167,936 rows -- its 1.0 GB of L2->LDS fills per launch, against 0.67 GB, cost more
+//  than overlapping one block's epilogue with the other's MFMAs gained)
+template <typename T> static inline int fc_bm() { return sizeof(T) == 2 ? 256 : 128; }
 template <typename T, int EPI>
 static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) == 2) return launch_gemm_nt256<EPI>(a, st);
@@ -328,7 +331,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
             ProfScope ps(CP_K_FC_FWD, st);
             CK((launch_fc_gemm<T, EPI_FWD>(a, st)));
         }
-        if (int e = finalize(L, (int)((N + FcTile<T>::BM - 1) / FcTile<T>::BM), (double)N)) return e;
+        if (int e = finalize(L, (int)((N + fc_bm<T>() - 1) / fc_bm<T>()), (double)N)) return e;
     }
     // projection 512 -> 16 (weights padded to 32 rows)
     {
@@ -436,7 +439,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     float* coef = (float*)(base + w.coef);
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
-    const int tiles_n = (int)((N + FcTile<T>::BM - 1) / FcTile<T>::BM);
+    const int tiles_n = (int)((N + fc_bm<T>() - 1) / fc_bm<T>());
     int conv_dgrad_rows = 0;
     const PreReduce pre{partials, (float*)(base + w.partials2), st};
 

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output (gpurun_out/...) into the small summaries committed under profiles/.
+
+  kernel stats :  python tools/parse_profile.py stats  <dir with *_kernel_stats.csv>  profiles/rNN_kernel_stats.csv
+  HBM traffic  :  python tools/parse_profile.py traffic <fetch dir> <write dir> profiles/rNN_traffic.json
+
+Traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from
+separate --pmc passes (they do not fit one pass), are in KiB, and on gfx950 FETCH_SIZE reports exactly half
+the bytes of a wide coalesced read stream, so  bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def one(pattern):
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        raise SystemExit(f"no file matches {pattern}")
+    return files[0]
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]][0] += float(r["Counter_Value"])
+            agg[r["Kernel_Name"]][1] += 1
+    return agg
+
+
+def main():
+    mode = sys.argv[1]
+    if mode == "stats":
+        shutil.copy(one(os.path.join(sys.argv[2], "**", "*_kernel_stats.csv")), sys.argv[3])
+    elif mode == "traffic":
+        f = per_kernel(one(os.path.join(sys.argv[2], "**", "*_counter_collection.csv")), "FETCH_SIZE")
+        w = per_kernel(one(os.path.join(sys.argv[3], "**", "*_counter_collection.csv")), "WRITE_SIZE")
+        out = {}
+        for k in sorted(set(f) | set(w)):
+            fb = 2 * f[k][0] / max(f[k][1], 1) * 1024 if k in f else 0.0
+            wb = w[k][0] / max(w[k][1], 1) * 1024 if k in w else 0.0
+            out[k] = dict(launches=int(max(f[k][1] if k in f else 0, w[k][1] if k in w else 0)),
+                          read_bytes_per_launch=fb, write_bytes_per_launch=wb, hbm_bytes_per_launch=fb + wb)
+        json.dump(dict(note="2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950 correction, separate PMC passes)",
+                       kernels=out), open(sys.argv[4], "w"), indent=1)
+        tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
+        print("total HBM bytes over the profiled run: %.2f GB" % (tot / 1e9))
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == "__main__":
+    main()
