@@ -563,7 +563,17 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             const int S = (int)(strips < cap ? strips : cap);
             ca.partials = slabs;
             hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, slabs, S, 64, 192, 64, (const float*)nullptr,
+            // up to 768 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
+            // unused tail of the slab buffer), then the scatter kernel walks 32 instead of 768
+            const float* sl = slabs;
+            int ns = S;
+            if (S > 2 * REDUCE_SLICES) {
+                float* folded = slabs + (size_t)S * 64 * 192;
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(64 * 192 / 64, REDUCE_SLICES), dim3(256), 0, st, slabs, S, 64 * 192, folded);
+                sl = folded;
+                ns = REDUCE_SLICES;
+            }
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, sl, ns, 64, 192, 64, (const float*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2);
             CKL("conv2_wgrad_kernel");
         }

@@ -38,7 +38,14 @@ template <typename T> struct ConvGeo {
     static constexpr int RPP = 256 / CPR;                // rows handled per pass by 256 threads
     static constexpr int WPITCH = 192 * (int)sizeof(T) + 16;
     static constexpr int CPITCH = ROWB + 16;
-    __device__ static __forceinline__ int swz(int row) { return sizeof(T) == 2 ? ((row >> 1) & 7) : (row & 15); }
+    // The 16 lanes of a ds_read_b128 group read output rows that are distinct mod 16, but image rows
+    // skip 2 at every window boundary, so the swizzle is keyed on the "dense" row index
+    // d = row - 2*(row/14) (= output row + tap for every row a fragment read touches; d and row have
+    // the same parity, which is what selects the bank half of a 128-byte row).
+    __device__ static __forceinline__ int swz(int row) {
+        const int d = row - 2 * (row / 14);
+        return sizeof(T) == 2 ? ((d >> 1) & 7) : (d & 15);
+    }
     __device__ static __forceinline__ int img_off(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
 };
 

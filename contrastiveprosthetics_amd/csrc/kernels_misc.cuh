@@ -331,8 +331,19 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
     const int64_t total = (int64_t)p_valid * Q;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int p = (int)(i / Q), q = (int)(i % Q);
-        float acc = 0.f;
-        for (int k = 0; k < S; ++k) acc += slabs[((int64_t)k * P + p) * Q + q];
+        // four independent chains keep several slab loads in flight (a single chain is latency-bound)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int64_t sstride = (int64_t)P * Q;
+        const float* src = slabs + (int64_t)p * Q + q;
+        int k = 0;
+        for (; k + 4 <= S; k += 4) {
+            a0 += src[(k + 0) * sstride];
+            a1 += src[(k + 1) * sstride];
+            a2 += src[(k + 2) * sstride];
+            a3 += src[(k + 3) * sstride];
+        }
+        for (; k < S; ++k) a0 += src[k * sstride];
+        float acc = (a0 + a1) + (a2 + a3);
         if (mode == 2) {
             const int tap = q >> 6, ii = q & 63;
             const int base = (p * 64 + ii) * 9;
