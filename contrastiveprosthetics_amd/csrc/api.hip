@@ -120,19 +120,22 @@ struct WS {
     size_t wfc[CP_N_FC], bfc[CP_N_FC], wfc_t[CP_N_FC];
     size_t wlast, blast, wlast_t, dzsum;
     size_t slabs;            // f32
+    size_t praw;             // f32 [512][768]: raw (un-fixed) weight-gradient product of the current layer
     size_t head_part;        // f32
     size_t total;
     size_t partials_floats, slabs_floats;
 };
 static const size_t kSlabFloats = (size_t)64 * 512 * 512 + 1024;   // 64 splits of a 512x512 (or 40 of a 512x768) f32 slab
 static const int kHeadBlocksMax = 1024;
+static const int kSumSlices = 16;           // row slices (= partial rows) of bn_bwd_sums_from_wgrad_kernel
 
 static WS carve(int64_t N, int dtype, float dp) {
     WS w;
     const size_t es = dtype == CP_BF16 ? 2 : 4;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
-    for (int l = 0; l < CP_N_BN; ++l) w.act[l] = take((size_t)N * (l < 2 ? 768 : 512) * es);
+    // (conv1's output is never stored: act[0] is empty, its consumers recompute it from x)
+    for (int l = 0; l < CP_N_BN; ++l) w.act[l] = take(l == 0 ? 0 : (size_t)N * (l < 2 ? 768 : 512) * es);
     for (int i = 0; i < 4; ++i) w.u[i] = dp > 0.f ? take((size_t)N * 512 * es) : 0;
     for (int i = 0; i < 2; ++i) w.gbuf[i] = take((size_t)N * 768 * es);
     w.dz = take((size_t)N * 64 * es);
@@ -154,6 +157,7 @@ static WS carve(int64_t N, int dtype, float dp) {
     w.dzsum = take(64 * 4);
     w.slabs_floats = kSlabFloats;
     w.slabs = take(kSlabFloats * 4);
+    w.praw = take((size_t)512 * 768 * 4);
     w.head_part = take((size_t)kHeadBlocksMax * HEAD_PART * 4);
     w.total = o;
     return w;
@@ -441,6 +445,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     const int tiles_n = (int)((N + fc_bm<T>() - 1) / fc_bm<T>());
     int conv_dgrad_rows = 0;
+    int stat_rows = tiles_n;     // partial rows holding the BN-backward sums for the next bn_bwd_finalize
     const PreReduce pre{partials, (float*)(base + w.partials2), st};
 
     {
@@ -475,12 +480,21 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         int S;
         split_rows(N, 128, &S, &ta.rows_per_split);
         CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0);
+        float* praw = (float*)(base + w.praw);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
+                           drop ? (float*)nullptr : praw);
         CKL("reduce_slabs(last)");
+        if (!drop) {
+            // BN-backward sums of fc7's BN from the projection's weight gradient (no N-sized read)
+            hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials,
+                               CP_D_E, 512, 0);
+            CKL("bn_bwd_sums_from_wgrad_kernel(last)");
+            stat_rows = 1;
+        }
         GemmNTArgs a{};
         a.A = dz; a.lda = 64; a.M = N; a.K = 64;
         a.W = base + w.wlast_t; a.F = 512;
-        a.C = cur; a.ldc = 512; a.R = act(8); a.ldr = 512; a.partials = partials;
+        a.C = cur; a.ldc = 512; a.R = drop ? act(8) : nullptr; a.ldr = 512; a.partials = partials;
         if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
         CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
     }
@@ -489,7 +503,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         const int i = L - 2, Lp = L - 1, K = fcK(i);
         {
             ProfScope ps(CP_K_BN_BWD, st);
-            int nr = tiles_n;
+            int nr = stat_rows;
             const float* pp = pre(nr, 2 * 512);
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(256), 0, st, pp, nr, (double)N, stats(L), coef,
                                g->bn_g[L], g->bn_b[L], 512, 1);
@@ -523,14 +537,23 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         }
         {
             ProfScope ps(CP_K_REDUCE_SLABS, st);
+            float* praw = (float*)(base + w.praw);
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
-                               i == 0 ? 1 : 0);
+                               i == 0 ? 1 : 0, in_drop ? (float*)nullptr : praw);
             CKL("reduce_slabs(fc)");
+            if (!in_drop) {
+                // no dropout between this layer and the previous BN: its backward sums follow from P = g_y^T r
+                // (just reduced), W and db -- the data-gradient launch below then reads no saved activation
+                hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(K / 64, kSumSlices), dim3(256), 0, st, praw, p->fc_w[i],
+                                   g->fc_b[i], partials, 512, K, i == 0 ? 1 : 0);
+                CKL("bn_bwd_sums_from_wgrad_kernel");
+            }
         }
+        stat_rows = in_drop ? tiles_n : kSumSlices;
         GemmNTArgs a{};
         a.A = cur; a.lda = 512; a.M = N; a.K = 512;
         a.W = base + w.wfc_t[i]; a.F = K;
-        a.C = nxt; a.ldc = K; a.R = act(Lp); a.ldr = K; a.partials = partials;
+        a.C = nxt; a.ldc = K; a.R = in_drop ? act(Lp) : nullptr; a.ldr = K; a.partials = partials;
         if (in_drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
         {
             ProfScope ps(CP_K_FC_DGRAD, st);
@@ -542,7 +565,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     {
         {
             ProfScope ps(CP_K_BN_BWD, st);
-            int nr = tiles_n;
+            int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
             const float* pp = pre(nr, 2 * 768);
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, (double)R12, stats(1), coef,
                                g->bn_g[1], g->bn_b[1], 64, 12);
@@ -574,7 +597,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 ns = REDUCE_SLICES;
             }
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, sl, ns, 64, 192, 64, (const float*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2);
+                               (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2, (float*)nullptr);
             CKL("conv2_wgrad_kernel");
         }
         conv_dgrad_rows = conv_grid<T>(N);

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
                     for (int e = 0; e < EPC; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
                 } else {
                     float rv[EPC];
-                    uint4 rc = *(const uint4*)(Rg + m * a.ldr + f);
+                    uint4 rc = make_uint4(0, 0, 0, 0);
+                    if (a.R != nullptr) rc = *(const uint4*)(Rg + m * a.ldr + f);   // nullptr: sums come from the weight gradient
                     D::unpack(rc, rv);
                     if (a.dp_thresh != 0) {
 #pragma unroll
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
                 *(uint4*)(Cg + m * a.ldc + f) = c;
             }
         }
+        if (EPI == EPI_DGRAD && a.R == nullptr) return;
         // block column sums: red[which][rr][col]
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {

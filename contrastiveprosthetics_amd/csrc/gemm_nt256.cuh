@@ -183,8 +183,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
     const T* Rg = (const T*)a.R;
     // the saved-activation chunks of all 16 passes are independent loads: issue them together (the
     // accumulators are dead here, registers are plentiful) instead of one dependent load per pass
+    // (R == nullptr: the caller derives the BN-backward sums from the weight gradient instead --
+    //  bn_bwd_sums_from_wgrad_kernel -- and this launch neither reads R nor reduces anything)
+    const bool with_stats = (EPI == EPI_FWD) || (a.R != nullptr);
     uint4 rpre[BM / RPP];
-    if constexpr (EPI == EPI_DGRAD) {
+    if (EPI == EPI_DGRAD && with_stats) {
 #pragma unroll
         for (int p = 0; p < BM / RPP; ++p) {
             int64_t m = m0 + rr + p * RPP;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
                 for (int e = 0; e < EPC; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
             } else {
                 float rv[EPC];
-                const uint4 rc = rpre[p];
+                const uint4 rc = with_stats ? rpre[p] : make_uint4(0, 0, 0, 0);
                 D::unpack(rc, rv);
                 if (a.dp_thresh != 0) {
 #pragma unroll
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
             *(uint4*)(Cg + m * a.ldc + f) = c;
         }
     }
+    if (!with_stats) return;
     // lanes l and l+32 of a wave own the same 8 columns: combine, then one row of sums per wave
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {

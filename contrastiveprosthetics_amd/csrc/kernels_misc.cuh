@@ -327,7 +327,8 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ partials, in
 // ------------------------------------------------------------------------------------
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int P, int Q, int p_valid,
                                     const float* __restrict__ s, const float* __restrict__ t,
-                                    const float* __restrict__ dbsum, float* __restrict__ grad, int mode) {
+                                    const float* __restrict__ dbsum, float* __restrict__ grad, int mode,
+                                    float* __restrict__ raw) {
     const int64_t total = (int64_t)p_valid * Q;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int p = (int)(i / Q), q = (int)(i % Q);
@@ -344,6 +345,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
         }
         for (; k < S; ++k) a0 += src[k * sstride];
         float acc = (a0 + a1) + (a2 + a3);
+        if (raw != nullptr) raw[i] = acc;              // un-fixed product g_y^T r, input of bn_bwd_sums_from_wgrad_kernel
         if (mode == 2) {
             const int tap = q >> 6, ii = q & 63;
             const int base = (p * 64 + ii) * 9;
@@ -356,5 +358,41 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
             if (s != nullptr) acc = fmaf(s[ch], acc, t[ch] * dbsum[p]);
             grad[dst] = acc;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BN-backward sums of the PREVIOUS layer without touching any N-sized tensor.  With g_v = g_y W
+// (no dropout in between) and P = g_y^T r the raw weight-gradient product of this layer:
+//     S1[k] = sum_n g_v[n][k]          = sum_j W[j][k] * db[j]          (db = column sums of g_y)
+//     S2[k] = sum_n g_v[n][k] r[n][k]  = sum_j W[j][k] * P[j][k]
+// out: gridDim.y "partial rows" [2][Kp] in the layout bn_bwd_finalize_kernel consumes (row y sums the
+// j-slice y), so the reduction over j runs on Kp/64 x gridDim.y blocks instead of a handful.
+//   mode 1 (fc1): P is in the internal k' = w*64 + c order, W in the reference order k = c*12 + w.
+// grid (Kp/64, slices) blocks of 256 threads (64 columns x 4 row lanes).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_sums_from_wgrad_kernel(const float* __restrict__ P, const float* __restrict__ W,
+                                                                     const float* __restrict__ db, float* __restrict__ out,
+                                                                     int F, int Kp, int mode) {
+    __shared__ double red[2][4][64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+    const int kp = blockIdx.x * 64 + cl;
+    const int k = mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;
+    const int per = (F + gridDim.y - 1) / gridDim.y;
+    const int j0 = blockIdx.y * per, j1 = (j0 + per < F) ? j0 + per : F;
+    double s1 = 0, s2 = 0;
+#pragma unroll 4
+    for (int j = j0 + g; j < j1; j += 4) {
+        const double w = (double)W[(int64_t)j * Kp + k];
+        s1 += w * (double)db[j];
+        s2 += w * (double)P[(int64_t)j * Kp + kp];
+    }
+    red[0][g][cl] = s1;
+    red[1][g][cl] = s2;
+    __syncthreads();
+    if (g == 0) {
+        float* row = out + (int64_t)blockIdx.y * 2 * Kp;
+        row[kp] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+        row[Kp + kp] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
     }
 }
