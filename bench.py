@@ -34,16 +34,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
-def gemm_model(kind: str, n: int, es: int):
+def gemm_model(kind: str, n: int, es: int, dropout: bool):
     """Algorithmic (bytes, flops) of ONE average launch of a GEMM kind over n windows (DESIGN.md
-    'roofline'): fc layers are 768->512 then 6 x 512->512; every activation/gradient element is
+    'measurement'): fc layers are 768->512 then 6 x 512->512; every activation/gradient element is
     moved once per kernel that must touch it (BN-barrier model)."""
     ks = [768] + [512] * 6
     flops = sum(2.0 * n * 512 * k for k in ks) / 7
     if kind == "fc_fwd":        # read input, write post-ReLU output
         byts = sum(n * es * (k + 512) for k in ks) / 7
-    elif kind == "fc_dgrad":    # read g_y, read saved activation (BN-backward sums), write g_v
-        byts = sum(n * es * (512 + 2 * k) for k in ks) / 7
+    elif kind == "fc_dgrad":    # read g_y, write g_v; the saved activation is read (BN-backward sums) only when
+        #                         dropout sits between the layers (fc5..fc7) -- otherwise the sums come from the
+        #                         weight gradient (bn_bwd_sums_from_wgrad_kernel) and no N-sized tensor is read for them
+        byts = sum(n * es * (512 + k + (k if (dropout and i >= 4) else 0)) for i, k in enumerate(ks)) / 7
     else:                       # fc_wgrad: read g_y and the layer input
         byts = sum(n * es * (512 + k) for k in ks) / 7
     return byts, flops
@@ -192,7 +194,7 @@ def main():
         dom = max(gemm_kinds, key=lambda k: prof.get(k, (0.0, 0))[0])
         ms, launches = prof[dom]
         avg_s = ms / launches / 1e3
-        byts, flops = gemm_model(dom, N, es)
+        byts, flops = gemm_model(dom, N, es, args.dp_emg > 0)
         gbs = byts / avg_s / 1e9
         tfl = flops / avg_s / 1e12
         mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
