@@ -10,6 +10,7 @@
 #include "common.cuh"
 #include "gemm_nt.cuh"
 #include "gemm_nt256.cuh"
+#include "gemm_nt256p.cuh"
 #include "gemm_tn.cuh"
 #include "gemm_tn256.cuh"
 #include "kernels_misc.cuh"
@@ -58,18 +59,18 @@ struct ProfScope {
         if (g_prof.on && ((g_prof.mask >> kind) & 1) && g_prof.used < g_prof.cap) {
             idx = g_prof.used++;
             g_prof.kind[idx] = kind;
-            hipEventRecord(g_prof.ev[2 * idx], st);
+            (void)hipEventRecord(g_prof.ev[2 * idx], st);
         }
     }
     ~ProfScope() {
-        if (idx >= 0) hipEventRecord(g_prof.ev[2 * idx + 1], st);
+        if (idx >= 0) (void)hipEventRecord(g_prof.ev[2 * idx + 1], st);
     }
 };
 
 extern "C" int cp_profile_enable(uint64_t kind_mask, int32_t max_records) {
     if (max_records <= 0) return fail(CP_ERR_ARG, "cp_profile_enable args");
     if (g_prof.cap < max_records) {
-        for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+        for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
         delete[] g_prof.ev;
         delete[] g_prof.kind;
         g_prof.ev = new hipEvent_t[2 * (size_t)max_records];
@@ -225,10 +226,18 @@ static inline int grid_rows(int64_t rows, int rows_per_block, int cap) {
 //  512x512 layer at 167,936 rows -- its 1.0 GB of L2->LDS fills per launch, against 0.67 GB, cost more
 //  than overlapping one block's epilogue with the other's MFMAs gained)
 template <typename T> static inline int fc_bm() { return sizeof(T) == 2 ? 256 : 128; }
+// bf16 launches without saved-activation statistics (every forward launch, and the data gradients whose
+// BN-backward sums come from the weight gradient) run the persistent kernel (gemm_nt256p.cuh).
+// *stat_rows = number of partial rows of column sums the launch wrote.
 template <typename T, int EPI>
-static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st) {
-    if constexpr (sizeof(T) == 2) return launch_gemm_nt256<EPI>(a, st);
-    else return launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI>(a, st);
+static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int* stat_rows = nullptr) {
+    if (stat_rows) *stat_rows = (int)((a.M + fc_bm<T>() - 1) / fc_bm<T>());
+    if constexpr (sizeof(T) == 2) {
+        if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows);
+        return launch_gemm_nt256<EPI>(a, st);
+    } else {
+        return launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI>(a, st);
+    }
 }
 
 // persistent conv strip kernels: blocks per CU allowed by their LDS footprint (bf16 70 KB, f32 116 KB)
@@ -331,11 +340,12 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         a.W = base + w.wfc[i]; a.F = 512;
         a.C = act(L); a.ldc = 512; a.bias = (float*)(base + w.bfc[i]); a.relu = 1;
         a.partials = partials;
+        int nrows = 0;
         {
             ProfScope ps(CP_K_FC_FWD, st);
-            CK((launch_fc_gemm<T, EPI_FWD>(a, st)));
+            CK((launch_fc_gemm<T, EPI_FWD>(a, st, &nrows)));
         }
-        if (int e = finalize(L, (int)((N + fc_bm<T>() - 1) / fc_bm<T>()), (double)N)) return e;
+        if (int e = finalize(L, nrows, (double)N)) return e;
     }
     // projection 512 -> 16 (weights padded to 32 rows)
     {

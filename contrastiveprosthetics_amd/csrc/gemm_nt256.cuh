@@ -148,7 +148,96 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
         if (s == 12345.678f) a.partials[0] = s;
         return;
     }
-    // ---- epilogue: accumulators -> bf16 tile in LDS -> 16-byte row segments to HBM ------------
+    // ---- register-direct epilogue (forward, and data gradients without statistics) -------------
+    // No LDS staging and no block barrier before the stores: a lane holds, per 32x32 tile, 4 runs of
+    // 4 consecutive features of ONE sample row (8 bytes as bf16); v_permlane32_swap exchanges the
+    // upper half-wave of run q with the lower half-wave of run q+1, after which every lane owns 8
+    // consecutive features = one 16-byte store (guide T21).  The BatchNorm column sums are folded
+    // over the wave's 4 sample tiles in registers (32 values per lane), then reduced across the 32
+    // sample lanes with a halving butterfly (31 shuffles per statistic: at step s a lane keeps the
+    // even/odd element of each pair according to bit s of its id and adds its partner's), which
+    // leaves lane r with the total of value r.
+    if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 8)) {
+        T* Cg = (T*)a.C;
+        float ps1[32], ps2[32];
+#pragma unroll
+        for (int v = 0; v < 32; ++v) ps1[v] = ps2[v] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float bq[16];
+            if constexpr (EPI == EPI_FWD) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *(const float4*)(a.bias + f0 + wf * 64 + i * 32 + 8 * q + 4 * h);
+                    bq[4 * q] = b4.x; bq[4 * q + 1] = b4.y; bq[4 * q + 2] = b4.z; bq[4 * q + 3] = b4.w;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int64_t m = m0 + ws * 128 + jj * 32 + r;
+                const bool live = m < a.M;
+                uint2 pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][jj][4 * q + e];
+                        if constexpr (EPI == EPI_FWD) {
+                            x += bq[4 * q + e];
+                            if (a.relu) x = fmaxf(x, 0.f);
+                        }
+                        v[e] = x;
+                    }
+                    pk[q] = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    if constexpr (EPI == EPI_FWD) {
+                        // statistics of the values as stored (bf16-rounded), tail rows excluded
+                        const float g0 = live ? __uint_as_float(pk[q].x << 16) : 0.f;
+                        const float g1 = live ? __uint_as_float(pk[q].x & 0xffff0000u) : 0.f;
+                        const float g2 = live ? __uint_as_float(pk[q].y << 16) : 0.f;
+                        const float g3 = live ? __uint_as_float(pk[q].y & 0xffff0000u) : 0.f;
+                        const int o = i * 16 + 4 * q;
+                        ps1[o] += g0; ps1[o + 1] += g1; ps1[o + 2] += g2; ps1[o + 3] += g3;
+                        ps2[o] = fmaf(g0, g0, ps2[o]); ps2[o + 1] = fmaf(g1, g1, ps2[o + 1]);
+                        ps2[o + 2] = fmaf(g2, g2, ps2[o + 2]); ps2[o + 3] = fmaf(g3, g3, ps2[o + 3]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    uint2 lo = pk[k], hi = pk[k + 1];
+                    const auto sx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+                    // lanes 0..31: features 8k..8k+7 of row r; lanes 32..63: features 8(k+1)..8(k+1)+7
+                    if (live)
+                        *(uint4*)(Cg + m * a.ldc + f0 + wf * 64 + i * 32 + 8 * (k + h)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                }
+            }
+        }
+        if constexpr (EPI == EPI_FWD) {
+            float* red = (float*)smem;           // [which][ws][BN]; the K loop's last barrier freed the LDS
+#pragma unroll
+            for (int s = 0, n = 32; s < 5; ++s, n >>= 1) {
+                const bool odd = (lane >> s) & 1;
+#pragma unroll
+                for (int p = 0; p < n / 2; ++p) {
+                    const float k1 = odd ? ps1[2 * p + 1] : ps1[2 * p], g1 = odd ? ps1[2 * p] : ps1[2 * p + 1];
+                    const float k2 = odd ? ps2[2 * p + 1] : ps2[2 * p], g2 = odd ? ps2[2 * p] : ps2[2 * p + 1];
+                    ps1[p] = k1 + __shfl_xor(g1, 1 << s, 64);
+                    ps2[p] = k2 + __shfl_xor(g2, 1 << s, 64);
+                }
+            }
+            // lane r of half h holds value r = i*16 + 4q + e  ->  feature wf*64 + i*32 + 8q + 4h + e
+            const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
+            red[(0 * 2 + ws) * BN + fl] = ps1[0];
+            red[(1 * 2 + ws) * BN + fl] = ps2[0];
+            __syncthreads();
+            const int which = tid / BN, col = tid % BN;
+            a.partials[(tile_m * 2 + which) * a.F + f0 + col] = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
+        }
+        return;
+    }
+    // ---- staged epilogue (data gradients that also reduce statistics against the saved activation):
+    //      accumulators -> bf16 tile in LDS -> 16-byte row segments to HBM ------------
     unsigned char* Cs = smem;
     float* red = (float*)(smem + C_BYTES);
 #pragma unroll

@@ -1,0 +1,287 @@
+// Persistent form of the bf16 256 x 256 NT GEMM (gemm_nt256.cuh) for the fc forward pass and for
+// data gradients that carry no statistics: ONE 8-wave block per CU for the whole launch, each block
+// walking its own list of output tiles.
+//
+// Why: with 64 KiB LDS stages only one block fits a CU, and a wave cannot retire before its stores
+// are acknowledged, so in the one-tile-per-block kernel every tile pays, back to back and with
+// nothing else on the CU, (a) the fill of its first stage, (b) its K loop, (c) the drain of its
+// 128 KiB of C stores.  Here the K loop is flattened across the block's tiles: the first stage of
+// tile n+1 is requested during the last K step of tile n, and tile n's stores -- written straight
+// from the accumulator registers, no LDS staging, no barrier (see the register-direct epilogue in
+// gemm_nt256.cuh) -- drain underneath tile n+1's first K step.
+//
+// Tile schedule (XCD-aware): block b runs on XCD b & 7; with j = b >> 3, tile_f = j % tiles_f is
+// FIXED for the block and round n handles sample tile ((n * J/tiles_f + j / tiles_f) * 8 + xcd), so the
+// tiles_f blocks that share one A tile run it in the same round on the same XCD (second read = L2
+// hit).  A fixed tile_f also means the folded weights' rows, the bias and the BatchNorm column sums
+// are per-block constants: the sums are carried in registers across tiles and written as ONE
+// partial row per block (row = (j / tiles_f) * 8 + xcd).
+#pragma once
+#include "gemm_nt256.cuh"
+
+// quad-permuted copy of w (DPP, no LDS crossbar)
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float w) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w), CTRL, 0xF, 0xF, true));
+}
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+// two f32 -> packed bf16 (one v_cvt_pk_bf16_f32); RELU: max(.,0) on the packed pair as signed 16-bit
+// integers (one v_pk_max_i16): a negative bf16, -0 included, is a negative int16, everything else keeps its bits
+template <bool RELU>
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    s16x2_t s = __builtin_bit_cast(s16x2_t, __builtin_convertvector(v, bf16x2_t));
+    if constexpr (RELU) {
+        const s16x2_t z = {0, 0};
+        s = __builtin_elementwise_max(s, z);
+    }
+    return __builtin_bit_cast(uint32_t, s);
+}
+
+// Register-direct epilogue of one tile (see gemm_nt256.cuh for the lane algebra): converts the accumulators
+// into 16-byte chunks (features i*32 + 8*(2kk + h) .. +7 of row mw0 + jj*32 + r; base = &C[mw0 + r][fw0 + 8h]),
+// stores them and folds the BatchNorm sums.  FULL = every row of the tile exists (only the launch's very
+// last sample tile can be ragged).  EPI_FWD: the accumulators already hold the bias (they were initialised
+// with it); ReLU is applied to the packed bf16 pairs; the sums are taken over the values as stored and
+// folded, per tile, from 32 to 8 values per statistic with two DPP butterfly steps inside each quad of lanes.
+template <int EPI, int MT, bool FULL>
+__device__ __forceinline__ void nt256p_convert(const GemmNTArgs& a, f32x16 (&acc)[2][MT], int64_t mw0,
+                                               bf16_t* base, int r, int lane, float (&qs1)[8], float (&qs2)[8]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float ps1[16], ps2[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) ps1[v] = ps2[v] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < MT; ++jj) {
+            const bool live = FULL || (mw0 + jj * 32 + r) < a.M;
+            uint2 pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pk[q].x = cvt_pk_bf16<EPI == EPI_FWD>(acc[i][jj][4 * q], acc[i][jj][4 * q + 1]);
+                pk[q].y = cvt_pk_bf16<EPI == EPI_FWD>(acc[i][jj][4 * q + 2], acc[i][jj][4 * q + 3]);
+                if constexpr (EPI == EPI_FWD) {
+                    float g0 = __uint_as_float(pk[q].x << 16), g1 = __uint_as_float(pk[q].x & 0xffff0000u);
+                    float g2 = __uint_as_float(pk[q].y << 16), g3 = __uint_as_float(pk[q].y & 0xffff0000u);
+                    if (!live) g0 = g1 = g2 = g3 = 0.f;
+                    const int o = 4 * q;
+                    ps1[o] += g0; ps1[o + 1] += g1; ps1[o + 2] += g2; ps1[o + 3] += g3;
+                    ps2[o] = fmaf(g0, g0, ps2[o]); ps2[o + 1] = fmaf(g1, g1, ps2[o + 1]);
+                    ps2[o + 2] = fmaf(g2, g2, ps2[o + 2]); ps2[o + 3] = fmaf(g3, g3, ps2[o + 3]);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * kk].x, pk[2 * kk + 1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * kk].y, pk[2 * kk + 1].y, false, false);
+                // lanes 0..31: features 16kk..16kk+7 of row r; lanes 32..63: features 16kk+8..16kk+15
+                const uint4 c = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                if (live) *(uint4*)(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk) = c;
+            }
+        }
+        if constexpr (EPI == EPI_FWD) {
+            // values v = i*16 + 4q + e: two butterfly steps inside each quad of lanes, 16 -> 4 per statistic
+            const bool o0 = lane & 1, o1 = (lane >> 1) & 1;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float k1 = o0 ? ps1[2 * p + 1] : ps1[2 * p], g1 = o0 ? ps1[2 * p] : ps1[2 * p + 1];
+                const float k2 = o0 ? ps2[2 * p + 1] : ps2[2 * p], g2 = o0 ? ps2[2 * p] : ps2[2 * p + 1];
+                ps1[p] = k1 + dpp_quad<0xB1>(g1);        // quad_perm [1,0,3,2]
+                ps2[p] = k2 + dpp_quad<0xB1>(g2);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float k1 = o1 ? ps1[2 * p + 1] : ps1[2 * p], g1 = o1 ? ps1[2 * p] : ps1[2 * p + 1];
+                const float k2 = o1 ? ps2[2 * p + 1] : ps2[2 * p], g2 = o1 ? ps2[2 * p] : ps2[2 * p + 1];
+                qs1[4 * i + p] += k1 + dpp_quad<0x4E>(g1);       // quad_perm [2,3,0,1]
+                qs2[4 * i + p] += k2 + dpp_quad<0x4E>(g2);
+            }
+        }
+    }
+}
+
+// MT = 32-row sample tiles per wave: the block's tile is (64 * MT) x 256.  Measured at 167,936 x 512 x 512:
+// MT = 3 (7 rounds of 192 rows instead of 6 of 256: 12.5 % fewer padded rows) ran no faster, its 30 % more
+// weight-tile refills cost what the rounding saved; holding a converted 192-row tile in 48 registers to
+// release its stores two per K step of the next tile made hipcc spill (118-280 VGPRs) and ran 1.4-1.8x
+// slower.  The launcher therefore uses MT = 4.
+template <int EPI, int MT>
+__global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
+    using T = bf16_t;
+    constexpr int BM = 64 * MT, BN = 256, BK = 64, EPC = 8;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + W_BYTES;
+    constexpr int LDS_BYTES = 2 * STAGE + 4 * BN * 4 + BN * 4;       // ring + [which][ws][BN] sums + bias
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    float* red = (float*)(smem + 2 * STAGE);
+    float* bias_s = red + 4 * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_f = a.F / BN;
+    const int64_t tiles_m = (a.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3, J = gridDim.x >> 3;
+    const int tile_f = j % tiles_f, jm = j / tiles_f;
+    const int64_t stride_m = (int64_t)(J / tiles_f) * 8;
+    int64_t tile_m = (int64_t)jm * 8 + xcd;
+    if (tile_m >= tiles_m) return;
+    const int f0 = tile_f * BN;
+    const int ws = wave >> 2, wf = wave & 3;
+
+    const T* __restrict__ Ag = (const T*)a.A;
+    const T* __restrict__ Wg = (const T*)a.W;
+    const int lrow = lane >> 3, pch = lane & 7;
+    const T* asrc[MT];
+    const T* wsrc[4];
+    auto set_src = [&](int64_t tm) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = (wave + 8 * i) * 8 + lrow;
+            const int lch = pch ^ ((row >> 1) & 7);
+            int64_t m = tm * BM + row;
+            if (m >= a.M) m = a.M - 1;                               // clamp: such rows are never stored
+            asrc[i] = Ag + m * a.lda + lch * EPC;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave + 8 * i) * 8 + lrow;
+        const int lch = pch ^ ((row >> 1) & 7);
+        wsrc[i] = Wg + (int64_t)(f0 + row) * a.K + lch * EPC;
+    }
+    set_src(tile_m);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage = [&](int buf, int kt) {
+        const uint32_t As = lds0 + buf * STAGE;
+        const uint32_t Ws = As + A_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rg = wave_u + 8 * i;
+            if (i < MT) glds16(asrc[i] + k0, As + rg * 1024);
+            glds16(wsrc[i] + k0, Ws + rg * 1024);
+        }
+    };
+
+    const int nk = a.K / BK;
+    if (EPI == EPI_FWD && tid < BN) bias_s[tid] = a.bias[f0 + tid];
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // BatchNorm column sums carried across the block's tiles: value v = 4p + (lane & 3), v = i*16 + 4q + e
+    float qs1[8], qs2[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) qs1[p] = qs2[p] = 0.f;
+    T* Cg = (T*)a.C;
+    int buf = 0;
+
+    while (true) {
+        const int64_t m0 = tile_m * BM;
+        const int64_t next_m = tile_m + stride_m;
+        const bool has_next = next_m < tiles_m;
+        f32x16 acc[2][MT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x16 b0;
+            if constexpr (EPI == EPI_FWD) {
+                // accumulators start at the bias: register g of a 32x32 tile is feature 8*(g>>2) + 4h + (g&3)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *(const float4*)(bias_s + wf * 64 + i * 32 + 8 * q + 4 * h);
+                    b0[4 * q] = b4.x; b0[4 * q + 1] = b4.y; b0[4 * q + 2] = b4.z; b0[4 * q + 3] = b4.w;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) b0[g] = 0.f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < MT; ++jj) acc[i][jj] = b0;
+        }
+
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+            else if (has_next) { set_src(next_m); stage(buf ^ 1, 0); }
+            const unsigned char* As = smem + buf * STAGE;
+            const unsigned char* Ws = As + A_BYTES;
+            uint4 fw[2][2], fs[2][MT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fw[0][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, h));
+#pragma unroll
+            for (int jj = 0; jj < MT; ++jj) fs[0][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, h));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        fw[nxt][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, 2 * (ks + 1) + h));
+#pragma unroll
+                    for (int jj = 0; jj < MT; ++jj)
+                        fs[nxt][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, 2 * (ks + 1) + h));
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < MT; ++jj) mma_chunk<T>(fw[cur][i], fs[cur][jj], acc[i][jj]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            // the stage requested above has had this step's MFMAs to land; every wave is done reading buf
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+
+        {
+            const int64_t mw0 = m0 + ws * (BM / 2);
+            T* base = Cg + (mw0 + r) * a.ldc + f0 + wf * 64 + 8 * h;
+            if (m0 + BM > a.M) nt256p_convert<EPI, MT, false>(a, acc, mw0, base, r, lane, qs1, qs2);
+            else nt256p_convert<EPI, MT, true>(a, acc, mw0, base, r, lane, qs1, qs2);
+        }
+        if (!has_next) break;
+        tile_m = next_m;
+    }
+
+    if constexpr (EPI == EPI_FWD) {
+        // remaining butterfly steps (lane bits 2..4), once per block
+#pragma unroll
+        for (int s = 2, n = 8; s < 5; ++s, n >>= 1) {
+            const bool odd = (lane >> s) & 1;
+#pragma unroll
+            for (int p = 0; p < n / 2; ++p) {
+                const float k1 = odd ? qs1[2 * p + 1] : qs1[2 * p], g1 = odd ? qs1[2 * p] : qs1[2 * p + 1];
+                const float k2 = odd ? qs2[2 * p + 1] : qs2[2 * p], g2 = odd ? qs2[2 * p] : qs2[2 * p + 1];
+                qs1[p] = k1 + __shfl_xor(g1, 1 << s, 64);
+                qs2[p] = k2 + __shfl_xor(g2, 1 << s, 64);
+            }
+        }
+        // lane r of half h holds value r = i*16 + 4q + e  ->  feature wf*64 + i*32 + 8q + 4h + e
+        const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
+        red[(0 * 2 + ws) * BN + fl] = qs1[0];
+        red[(1 * 2 + ws) * BN + fl] = qs2[0];
+        __syncthreads();
+        const int which = tid / BN, col = tid % BN;
+        const int64_t prow = (int64_t)jm * 8 + xcd;
+        a.partials[(prow * 2 + which) * a.F + f0 + col] = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
+    }
+}
+
+// One block per CU in whole XCD rows.  *stat_rows = partial rows written (EPI_FWD).  EPI_FWD always applies
+// ReLU (every fc layer of the reference has one; the projection runs the 128-tile kernel).
+template <int EPI>
+static inline hipError_t launch_gemm_nt256p(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
+    const int tiles_f = a.F / 256;
+    const int J = 32 - (32 % tiles_f);                       // blocks per XCD, a multiple of tiles_f
+    const int64_t slots = (int64_t)(J / tiles_f) * 8;        // sample tiles per round
+    const int64_t tiles_m = (a.M + 255) / 256;
+    if (stat_rows) *stat_rows = (int)(tiles_m < slots ? tiles_m : slots);
+    hipLaunchKernelGGL((gemm_nt256p_kernel<EPI, 4>), dim3(8 * J), dim3(512), 0, st, a);
+    return hipGetLastError();
+}

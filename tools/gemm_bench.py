@@ -25,16 +25,17 @@ partials = torch.empty(4 * (M // 128 + 8) * F, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 
 
-def run(kind, dbg, iters=20):
+def run(kind, dbg, iters=20, with_r=True):
     out = slabs if kind == 2 else C
     w = R if kind == 2 else W           # wgrad: Y operand is [M][F]
+    rp = R.data_ptr() if with_r else 0
     for _ in range(3):
         _lib.check(lib.cp_debug_gemm(1, kind, M, K, F, A.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr(),
-                                     R.data_ptr(), partials.data_ptr(), dbg, st), "cp_debug_gemm")
+                                     rp, partials.data_ptr(), dbg, st), "cp_debug_gemm")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        lib.cp_debug_gemm(1, kind, M, K, F, A.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr(), R.data_ptr(),
+        lib.cp_debug_gemm(1, kind, M, K, F, A.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr(), rp,
                           partials.data_ptr(), dbg, st)
     e1.record()
     torch.cuda.synchronize()
@@ -48,9 +49,35 @@ for kind in (0, 1, 2):
                       (4, "no staging loads")):
         if kind == 2 and dbg:
             continue
-        us = run(kind, dbg)
+        us = run(kind, dbg | (16 if dbg else 0))      # ablations exist in the one-tile-per-block kernel only
         print(f"{names[kind]:6s} {what:22s} {us:8.1f} us   {flops / us / 1e6:7.1f} TFLOP/s-equivalent")
+print(f"fwd    persistent, 192-row tiles, stores not deferred (dbg 64) {run(0, 64):8.1f} us")
+print(f"dgrad  persistent, 192-row tiles, stores not deferred, no statistics (dbg 64) {run(1, 64, with_r=False):8.1f} us")
+print(f"fwd    persistent, 256-row tiles (dbg 32) {run(0, 32):8.1f} us")
+print(f"dgrad  persistent, 256-row tiles, no statistics (dbg 32) {run(1, 32, with_r=False):8.1f} us")
+print(f"fwd    one tile per block, direct stores (dbg 16) {run(0, 16):8.1f} us")
+print(f"fwd    one tile per block, staged epilogue (dbg 24) {run(0, 24):8.1f} us")
+print(f"dgrad  no statistics (R = null): persistent {run(1, 0, with_r=False):8.1f} us")
+print(f"dgrad  no statistics, one tile per block: direct {run(1, 16, with_r=False):8.1f} us, staged {run(1, 24, with_r=False):8.1f} us")
 # numerical check of the forward against torch (bf16 inputs, f32 accumulate)
 lib.cp_debug_gemm(1, 0, M, K, F, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), R.data_ptr(), partials.data_ptr(), 0, st)
 ref = torch.relu(A[:4096].float() @ W.float().t())
 print("fwd max err vs torch:", float((C[:4096].float() - ref).abs().max()), "of", float(ref.abs().max()))
+
+bias.copy_(torch.randn(F, device=dev) * 0.1)
+for dbg in (0, 32, 24):
+    C.zero_()
+    partials.zero_()
+    lib.cp_debug_gemm(1, 0, M, K, F, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), R.data_ptr(), partials.data_ptr(), dbg, st)
+    tiles = (M + 255) // 256
+    p = partials[: tiles * 2 * F].view(tiles, 2, F).double().sum(0)
+    Cf = C.double()
+    ref = torch.relu(A[-3000:].float() @ W.float().t() + bias)
+    print(f"dbg {dbg}: tail-row max err {float((C[-3000:].float() - ref).abs().max()):.4f}; "
+          f"sum err {float((p[0] - Cf.sum(0)).abs().max()):.3e} of {float(Cf.sum(0).abs().max()):.3e}; "
+          f"sumsq err {float((p[1] - (Cf * Cf).sum(0)).abs().max()):.3e} of {float((Cf * Cf).sum(0).max()):.3e}")
+    del Cf
+Cd = torch.empty_like(C)
+lib.cp_debug_gemm(1, 1, M, K, F, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), 0, partials.data_ptr(), 0, st)
+lib.cp_debug_gemm(1, 1, M, K, F, A.data_ptr(), W.data_ptr(), Cd.data_ptr(), bias.data_ptr(), 0, partials.data_ptr(), 24, st)
+print("dgrad persistent == staged:", bool((C == Cd).all()))
