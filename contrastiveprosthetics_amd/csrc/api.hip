@@ -254,7 +254,7 @@ struct PreReduce {
     float* scratch;
     hipStream_t st;
     const float* operator()(int& nrows, int W) const {
-        if (nrows <= 2 * REDUCE_SLICES) return partials;
+        if (nrows <= 2 * REDUCE_SLICES) return partials;      // (128 rows finalized directly measured slower than reduce + finalize)
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(W / 64, REDUCE_SLICES), dim3(256), 0, st, partials, nrows, W, scratch);
         nrows = REDUCE_SLICES;
         return scratch;

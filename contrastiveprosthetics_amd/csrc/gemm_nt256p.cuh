@@ -16,6 +16,13 @@
 // hit).  A fixed tile_f also means the folded weights' rows, the bias and the BatchNorm column sums
 // are per-block constants: the sums are carried in registers across tiles and written as ONE
 // partial row per block (row = (j / tiles_f) * 8 + xcd).
+//
+// Measured and dropped on top of this kernel: applying the layer below's BatchNorm + ReLU backward in the
+// data-gradient epilogue (coefficients are known beforehand thanks to bn_bwd_sums_from_wgrad_kernel; the
+// saved activation was fetched in the store layout and un-swapped with the same permlane32 swap).  With
+// 128 accumulator registers live the fetched tile and the coefficients did not fit: 53-63 spilled VGPRs,
+// +160..220 us per launch against the 94 us of the separate pass it replaced (which already streams at
+// 5.5 TB/s).
 #pragma once
 #include "gemm_nt256.cuh"
 
