@@ -34,20 +34,35 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
+# profiler kind -> (the ONE kernel it times, as rocprofv3 names it; fc layer indices it runs on when dropout is on / off)
+GEMM_KERNELS = {
+    "fc_fwd": "gemm_nt256p_kernel<0, 4>",          # persistent, bias + ReLU + BN sums in the epilogue
+    "fc_dgrad": "gemm_nt256p_kernel<1, 4>",        # persistent, plain data gradient
+    "fc_dgrad_stats": "gemm_nt256_kernel<1>",      # dropout on the input: dropout mask + BN-backward sums vs the saved activation
+    "fc_wgrad": "gemm_tn256_kernel",
+}
+
+
 def gemm_model(kind: str, n: int, es: int, dropout: bool):
     """Algorithmic (bytes, flops) of ONE average launch of a GEMM kind over n windows (DESIGN.md
     'measurement'): fc layers are 768->512 then 6 x 512->512; every activation/gradient element is
-    moved once per kernel that must touch it (BN-barrier model)."""
+    moved once per kernel that must touch it (BN-barrier model).  Dropout sits on the inputs
+    of fc5..fc7: their data-gradient launches (kind fc_dgrad_stats) also read the saved activation; the
+    others (kind fc_dgrad) get the BN-backward sums from the weight gradient and read no N-sized tensor for them."""
     ks = [768] + [512] * 6
-    flops = sum(2.0 * n * 512 * k for k in ks) / 7
-    if kind == "fc_fwd":        # read input, write post-ReLU output
-        byts = sum(n * es * (k + 512) for k in ks) / 7
-    elif kind == "fc_dgrad":    # read g_y, write g_v; the saved activation is read (BN-backward sums) only when
-        #                         dropout sits between the layers (fc5..fc7) -- otherwise the sums come from the
-        #                         weight gradient (bn_bwd_sums_from_wgrad_kernel) and no N-sized tensor is read for them
-        byts = sum(n * es * (512 + k + (k if (dropout and i >= 4) else 0)) for i, k in enumerate(ks)) / 7
-    else:                       # fc_wgrad: read g_y and the layer input
-        byts = sum(n * es * (512 + k) for k in ks) / 7
+    if kind == "fc_fwd":            # read input, write post-ReLU output
+        layers, per = range(7), lambda k: k + 512
+    elif kind == "fc_dgrad":        # read g_y, write g_v
+        layers, per = (range(4) if dropout else range(7)), lambda k: 512 + k
+    elif kind == "fc_dgrad_stats":  # read g_y and the saved activation, write g_v
+        layers, per = (range(4, 7) if dropout else range(0)), lambda k: 512 + 2 * k
+    else:                           # fc_wgrad: read g_y and the layer input
+        layers, per = range(7), lambda k: 512 + k
+    layers = list(layers)
+    if not layers:
+        return 0.0, 0.0
+    byts = sum(n * es * per(ks[i]) for i in layers) / len(layers)
+    flops = sum(2.0 * n * 512 * ks[i] for i in layers) / len(layers)
     return byts, flops
 
 
@@ -162,7 +177,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    gemm_kinds = ["fc_fwd", "fc_dgrad", "fc_wgrad"]
+    gemm_kinds = ["fc_fwd", "fc_dgrad", "fc_dgrad_stats", "fc_wgrad"]
     eng.profile_enable(gemm_kinds, max_records=64 * (args.steps + 1))
     barrier()
     t0 = time.perf_counter()
@@ -201,20 +216,28 @@ def main():
         # HBM bytes per launch from the committed PMC profile of this same command (tools/parse_profile.py,
         # separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction); null if not profiled
         traffic = None
-        kname = {"fc_fwd": "gemm_nt256_kernel<0>", "fc_dgrad": "gemm_nt256_kernel<1>", "fc_wgrad": "gemm_tn256_kernel"}[dom]
+        kname = GEMM_KERNELS[dom]
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if args.dtype == "bf16" and B == 4096 and os.path.exists(tpath):
             for k, v in json.load(open(tpath))["kernels"].items():
                 if kname in k:
                     traffic = v["hbm_bytes_per_launch"]
+        per_kernel = {}
+        for k in gemm_kinds:
+            if k in prof and prof[k][1] > 0:
+                kb, kf = gemm_model(k, N, es, args.dp_emg > 0)
+                ks_ = prof[k][0] / prof[k][1] / 1e3
+                per_kernel[k] = dict(symbol=GEMM_KERNELS[k], launches=prof[k][1], avg_us=ks_ * 1e6, algorithmic_bytes=kb,
+                                     gbs=kb / ks_ / 1e9, hbm_frac=kb / ks_ / 1e9 / HBM_PEAK_GBS, tflops=kf / ks_ / 1e12)
         bound = "hbm" if byts / (HBM_PEAK_GBS * 1e9) >= flops / (mfma_peak * 1e12) else "mfma"
-        roof = dict(bound=bound, kernel=dom, launches=launches, avg_us=avg_s * 1e6,
+        roof = dict(bound=bound, kernel=dom, kernel_symbol=kname, launches=launches, avg_us=avg_s * 1e6,
                     achieved=gbs if bound == "hbm" else tfl, peak=HBM_PEAK_GBS if bound == "hbm" else mfma_peak,
                     unit="GB/s" if bound == "hbm" else "TFLOP/s",
                     frac=(gbs / HBM_PEAK_GBS) if bound == "hbm" else (tfl / mfma_peak), traffic=traffic,
                     algorithmic_bytes=byts,
                     mfma_tflops=tfl, mfma_frac=tfl / mfma_peak, hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
-                    gemm_ms_per_step={k: prof[k][0] / args.steps for k in gemm_kinds if k in prof})
+                    gemm_ms_per_step={k: prof[k][0] / args.steps for k in gemm_kinds if k in prof},
+                    per_kernel=per_kernel)
         rec = dict(metric="sEMG windows/sec contrastive step, 12-ch Ninapro", value=world * N * args.steps / elapsed,
                    unit="windows/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,

@@ -566,7 +566,9 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         a.C = nxt; a.ldc = K; a.R = in_drop ? act(Lp) : nullptr; a.ldr = K; a.partials = partials;
         if (in_drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
         {
-            ProfScope ps(CP_K_FC_DGRAD, st);
+            // two kinds = two kernels: with input dropout the launch also reduces the BN-backward sums against
+            // the saved activation (one-tile-per-block kernel), otherwise it is the persistent kernel
+            ProfScope ps(in_drop ? CP_K_FC_DGRAD_STATS : CP_K_FC_DGRAD, st);
             CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
         }
         T* tmp = cur; cur = nxt; nxt = tmp;

@@ -57,14 +57,19 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 template <int EPI, int MT, bool FULL>
 __device__ __forceinline__ void nt256p_convert(const GemmNTArgs& a, f32x16 (&acc)[2][MT], int64_t mw0,
                                                bf16_t* base, int r, int lane, float (&qs1)[8], float (&qs2)[8]) {
+    float ps1[2][16], ps2[2][16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float ps1[16], ps2[16];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) ps1[v] = ps2[v] = 0.f;
+        for (int v = 0; v < 16; ++v) ps1[i][v] = ps2[i][v] = 0.f;
+    // sample tile outermost: the four 16-byte stores that make up one 128-byte line of a row (i = 0,1 x
+    // kk = 0,1) leave back to back, so L2 merges them into one full-line write (with the feature half
+    // outermost the PMC pass showed 210 MB written per launch for 172 MB of output)
 #pragma unroll
-        for (int jj = 0; jj < MT; ++jj) {
-            const bool live = FULL || (mw0 + jj * 32 + r) < a.M;
+    for (int jj = 0; jj < MT; ++jj) {
+        const bool live = FULL || (mw0 + jj * 32 + r) < a.M;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             uint2 pk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -75,9 +80,9 @@ __device__ __forceinline__ void nt256p_convert(const GemmNTArgs& a, f32x16 (&acc
                     float g2 = __uint_as_float(pk[q].y << 16), g3 = __uint_as_float(pk[q].y & 0xffff0000u);
                     if (!live) g0 = g1 = g2 = g3 = 0.f;
                     const int o = 4 * q;
-                    ps1[o] += g0; ps1[o + 1] += g1; ps1[o + 2] += g2; ps1[o + 3] += g3;
-                    ps2[o] = fmaf(g0, g0, ps2[o]); ps2[o + 1] = fmaf(g1, g1, ps2[o + 1]);
-                    ps2[o + 2] = fmaf(g2, g2, ps2[o + 2]); ps2[o + 3] = fmaf(g3, g3, ps2[o + 3]);
+                    ps1[i][o] += g0; ps1[i][o + 1] += g1; ps1[i][o + 2] += g2; ps1[i][o + 3] += g3;
+                    ps2[i][o] = fmaf(g0, g0, ps2[i][o]); ps2[i][o + 1] = fmaf(g1, g1, ps2[i][o + 1]);
+                    ps2[i][o + 2] = fmaf(g2, g2, ps2[i][o + 2]); ps2[i][o + 3] = fmaf(g3, g3, ps2[i][o + 3]);
                 }
             }
 #pragma unroll
@@ -89,20 +94,23 @@ __device__ __forceinline__ void nt256p_convert(const GemmNTArgs& a, f32x16 (&acc
                 if (live) *(uint4*)(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk) = c;
             }
         }
-        if constexpr (EPI == EPI_FWD) {
-            // values v = i*16 + 4q + e: two butterfly steps inside each quad of lanes, 16 -> 4 per statistic
-            const bool o0 = lane & 1, o1 = (lane >> 1) & 1;
+    }
+    if constexpr (EPI == EPI_FWD) {
+        // values v = i*16 + 4q + e: two butterfly steps inside each quad of lanes, 16 -> 4 per statistic and half
+        const bool o0 = lane & 1, o1 = (lane >> 1) & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const float k1 = o0 ? ps1[2 * p + 1] : ps1[2 * p], g1 = o0 ? ps1[2 * p] : ps1[2 * p + 1];
-                const float k2 = o0 ? ps2[2 * p + 1] : ps2[2 * p], g2 = o0 ? ps2[2 * p] : ps2[2 * p + 1];
-                ps1[p] = k1 + dpp_quad<0xB1>(g1);        // quad_perm [1,0,3,2]
-                ps2[p] = k2 + dpp_quad<0xB1>(g2);
+                const float k1 = o0 ? ps1[i][2 * p + 1] : ps1[i][2 * p], g1 = o0 ? ps1[i][2 * p] : ps1[i][2 * p + 1];
+                const float k2 = o0 ? ps2[i][2 * p + 1] : ps2[i][2 * p], g2 = o0 ? ps2[i][2 * p] : ps2[i][2 * p + 1];
+                ps1[i][p] = k1 + dpp_quad<0xB1>(g1);        // quad_perm [1,0,3,2]
+                ps2[i][p] = k2 + dpp_quad<0xB1>(g2);
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const float k1 = o1 ? ps1[2 * p + 1] : ps1[2 * p], g1 = o1 ? ps1[2 * p] : ps1[2 * p + 1];
-                const float k2 = o1 ? ps2[2 * p + 1] : ps2[2 * p], g2 = o1 ? ps2[2 * p] : ps2[2 * p + 1];
+                const float k1 = o1 ? ps1[i][2 * p + 1] : ps1[i][2 * p], g1 = o1 ? ps1[i][2 * p] : ps1[i][2 * p + 1];
+                const float k2 = o1 ? ps2[i][2 * p + 1] : ps2[i][2 * p], g2 = o1 ? ps2[i][2 * p] : ps2[i][2 * p + 1];
                 qs1[4 * i + p] += k1 + dpp_quad<0x4E>(g1);       // quad_perm [2,3,0,1]
                 qs2[4 * i + p] += k2 + dpp_quad<0x4E>(g2);
             }

@@ -51,8 +51,8 @@ for kind in (0, 1, 2):
             continue
         us = run(kind, dbg | (16 if dbg else 0))      # ablations exist in the one-tile-per-block kernel only
         print(f"{names[kind]:6s} {what:22s} {us:8.1f} us   {flops / us / 1e6:7.1f} TFLOP/s-equivalent")
-print(f"fwd    persistent, 192-row tiles, stores not deferred (dbg 64) {run(0, 64):8.1f} us")
-print(f"dgrad  persistent, 192-row tiles, stores not deferred, no statistics (dbg 64) {run(1, 64, with_r=False):8.1f} us")
+
+
 print(f"fwd    persistent, 256-row tiles (dbg 32) {run(0, 32):8.1f} us")
 print(f"dgrad  persistent, 256-row tiles, no statistics (dbg 32) {run(1, 32, with_r=False):8.1f} us")
 print(f"fwd    one tile per block, direct stores (dbg 16) {run(0, 16):8.1f} us")

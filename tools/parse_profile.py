@@ -17,11 +17,44 @@ import shutil
 import sys
 
 
-def one(pattern):
+def one(pattern, required=True):
     files = glob.glob(pattern, recursive=True)
     if not files:
-        raise SystemExit(f"no file matches {pattern}")
+        if required:
+            raise SystemExit(f"no file matches {pattern}")
+        return None
     return files[0]
+
+
+def db_of(d):
+    """rocprofv3 of ROCm 7.2 writes a rocpd SQLite file (*_results.db) unless --output-format csv is given."""
+    import sqlite3
+    return sqlite3.connect(one(os.path.join(d, "**", "*_results.db")))
+
+
+def stats_from_db(d, out):
+    import math
+    con = db_of(d)
+    agg = collections.defaultdict(list)
+    for name, dur in con.execute("select name, duration from kernels"):
+        agg[name].append(float(dur))
+    total = sum(sum(v) for v in agg.values())
+    rows = sorted(agg.items(), key=lambda kv: -sum(kv[1]))
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for name, v in rows:
+            mean = sum(v) / len(v)
+            sd = math.sqrt(sum((x - mean) ** 2 for x in v) / len(v))
+            w.writerow([name, len(v), int(sum(v)), round(mean, 3), round(100 * sum(v) / total, 4), int(min(v)), int(max(v)), round(sd, 3)])
+
+
+def per_kernel_db(d, counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for name, val in db_of(d).execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+        agg[name][0] += float(val)
+        agg[name][1] += 1
+    return agg
 
 
 def per_kernel(path, counter):
@@ -36,10 +69,16 @@ def per_kernel(path, counter):
 def main():
     mode = sys.argv[1]
     if mode == "stats":
-        shutil.copy(one(os.path.join(sys.argv[2], "**", "*_kernel_stats.csv")), sys.argv[3])
+        src = one(os.path.join(sys.argv[2], "**", "*_kernel_stats.csv"), required=False)
+        if src:
+            shutil.copy(src, sys.argv[3])
+        else:
+            stats_from_db(sys.argv[2], sys.argv[3])
     elif mode == "traffic":
-        f = per_kernel(one(os.path.join(sys.argv[2], "**", "*_counter_collection.csv")), "FETCH_SIZE")
-        w = per_kernel(one(os.path.join(sys.argv[3], "**", "*_counter_collection.csv")), "WRITE_SIZE")
+        fc = one(os.path.join(sys.argv[2], "**", "*_counter_collection.csv"), required=False)
+        wc = one(os.path.join(sys.argv[3], "**", "*_counter_collection.csv"), required=False)
+        f = per_kernel(fc, "FETCH_SIZE") if fc else per_kernel_db(sys.argv[2], "FETCH_SIZE")
+        w = per_kernel(wc, "WRITE_SIZE") if wc else per_kernel_db(sys.argv[3], "WRITE_SIZE")
         out = {}
         for k in sorted(set(f) | set(w)):
             fb = 2 * f[k][0] / max(f[k][1], 1) * 1024 if k in f else 0.0
