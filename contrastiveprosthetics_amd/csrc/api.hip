@@ -17,6 +17,7 @@
 #include "conv_kernels.cuh"
 #include "head.cuh"
 #include "optim.cuh"
+#include "eval.cuh"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* what) {
@@ -428,6 +429,35 @@ extern "C" int cp_vote(const int32_t* pred, const int64_t* labels, int64_t B, in
     if (!pred || !labels || !curve || !y_pred || B <= 0 || V <= 0 || V > 32) return fail(CP_ERR_ARG, "cp_vote args");
     hipLaunchKernelGGL(vote_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, pred, labels, B, (int)V, curve, y_pred);
     CKL("vote_kernel");
+    return 0;
+}
+
+extern "C" int cp_subset_vote(const float* logits, const int64_t* labels, int64_t B, int32_t V, const uint8_t* masks,
+                              int64_t n_masks, int64_t* correct, int32_t* y_pred, void* stream) {
+    if (!logits || !labels || !masks || !correct || B <= 0 || B > 65535 || V <= 0 || V > SV_VMAX || n_masks <= 0)
+        return fail(CP_ERR_ARG, "cp_subset_vote args");
+    hipStream_t st = (hipStream_t)stream;
+    CK(hipMemsetAsync(correct, 0, (size_t)n_masks * V * sizeof(int64_t), st));
+    SubsetVoteArgs a{};
+    a.logits = logits; a.labels = labels; a.masks = masks; a.correct = (unsigned long long*)correct; a.y_pred = y_pred;
+    a.B = B; a.n_masks = n_masks; a.V = V;
+    const size_t lds = sv_lds_bytes(V);
+    static bool attr_set = false;
+    if (!attr_set) {      // > 64 KiB of dynamic LDS needs the opt-in once per process
+        CK(hipFuncSetAttribute((const void*)subset_vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sv_lds_bytes(SV_VMAX)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(subset_vote_kernel, dim3((unsigned)((n_masks + SV_MPB - 1) / SV_MPB), (unsigned)B), dim3(256), lds, st, a);
+    CKL("subset_vote_kernel");
+    return 0;
+}
+
+extern "C" int cp_confusion(const int32_t* y_pred, const int64_t* labels, int64_t n_groups, int64_t* counts, void* stream) {
+    if (!y_pred || !labels || !counts || n_groups <= 0) return fail(CP_ERR_ARG, "cp_confusion args");
+    const int64_t n = n_groups * SV_T;
+    const int g = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
+    hipLaunchKernelGGL(confusion_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, y_pred, labels, n, (unsigned long long*)counts);
+    CKL("confusion_kernel");
     return 0;
 }
 

@@ -112,6 +112,38 @@ def gather_groups(table: torch.Tensor, emg_rand: torch.Tensor, perm: torch.Tenso
     return out
 
 
+def subset_vote(logits: torch.Tensor, labels: torch.Tensor, B: int, V: int, masks: torch.Tensor, want_pred: bool = False):
+    """cp_subset_vote: logits (B*V,41,41) f32, labels (41) int64, masks (n,41) uint8 ->
+    correct (n,V) int64 [, y_pred (n,B,41) int32]  (README.md:11-19, code/models.py:146-163)."""
+    lib = _lib.load()
+    if logits.device.type != "cuda":
+        raise _lib.CpNativeError("contrastiveprosthetics_amd runs on an MI355X (device 'cuda') only; no CPU path")
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and tuple(logits.shape) == (B * V, CP_TASKS, CP_TASKS)
+    assert labels.dtype == torch.int64 and labels.numel() >= CP_TASKS and labels.is_contiguous()
+    masks = masks.to(device=logits.device, dtype=torch.uint8).reshape(-1, CP_TASKS).contiguous()
+    n = masks.shape[0]
+    correct = torch.empty(n, V, dtype=torch.int64, device=logits.device)
+    y_pred = torch.empty(n, B, CP_TASKS, dtype=torch.int32, device=logits.device) if want_pred else None
+    _lib.check(lib.cp_subset_vote(logits.data_ptr(), labels.data_ptr(), B, V, masks.data_ptr(), n, correct.data_ptr(),
+                                  y_pred.data_ptr() if want_pred else None,
+                                  torch.cuda.current_stream(logits.device).cuda_stream), "cp_subset_vote")
+    return (correct, y_pred) if want_pred else correct
+
+
+def confusion(y_pred: torch.Tensor, labels: torch.Tensor, counts: torch.Tensor = None) -> torch.Tensor:
+    """cp_confusion: counts (41,41) int64 += [labels[i % 41]][y_pred[i]]  (code/results.py:58)."""
+    lib = _lib.load()
+    if y_pred.device.type != "cuda":
+        raise _lib.CpNativeError("contrastiveprosthetics_amd runs on an MI355X (device 'cuda') only; no CPU path")
+    assert y_pred.dtype == torch.int32 and y_pred.is_contiguous() and y_pred.numel() % CP_TASKS == 0
+    assert labels.dtype == torch.int64 and labels.numel() >= CP_TASKS and labels.is_contiguous()
+    if counts is None:
+        counts = torch.zeros(CP_TASKS, CP_TASKS, dtype=torch.int64, device=y_pred.device)
+    _lib.check(lib.cp_confusion(y_pred.data_ptr(), labels.data_ptr(), y_pred.numel() // CP_TASKS, counts.data_ptr(),
+                                torch.cuda.current_stream(y_pred.device).cuda_stream), "cp_confusion")
+    return counts
+
+
 class Engine:
     def __init__(self, adabn: bool = True, dtype: str = "bf16", dp_emg: float = 0.0, device="cuda",
                  d_e: int = CP_D_E, seed: int = 0):

@@ -117,6 +117,24 @@ int cp_encoder_backward(const cp_config* cfg, const cp_params* p, const float* x
 int cp_vote(const int32_t* pred, const int64_t* labels, int64_t B, int32_t V, float* curve,
             int32_t* y_pred, void* stream);
 
+/* Class-subset evaluation for MANY subsets in one launch.  The reference's product
+ * use-case (README.md:11-19): at test time the user keeps a subset S of the 41 classes; only the EMG rows t in S
+ * and the class-encoding columns c in S of every 41 x 41 logits tile take part,
+ *     pred[b,v,t] = argmax_{c in S} logits[b*V+v, t, c]            (code/models.py:147, first maximum wins)
+ * followed by the prefix majority vote of code/models.py:151-163 (torch.mode: ties -> smallest class id).
+ * logits (B*V,41,41) f32 as Model.forward returns them in eval (what results.py:45 saves as logs.npy);
+ * labels (41) int64 = labels[:tasks]; masks (n_masks,41) uint8 (non-zero = member);
+ * correct (n_masks,V) int64 OVERWRITTEN with the number of (b, t in S) whose mode over the first w+1 samples
+ * equals labels[t] (accuracy = correct / (B*|S|); Model.voting_raw lays w = 0..V-1 out over win = 1..249);
+ * y_pred optional (n_masks,B,41) int32: mode over all V samples, -1 for rows outside S (results.py:51).
+ * V <= 64. */
+int cp_subset_vote(const float* logits, const int64_t* labels, int64_t B, int32_t V, const uint8_t* masks,
+                   int64_t n_masks, int64_t* correct, int32_t* y_pred, void* stream);
+
+/* sklearn.metrics.confusion_matrix(y_true, y_pred) of code/results.py:58 as counts:
+ * counts (41,41) int64 += 1 at [labels[i % 41]][y_pred[i]] for i < n_groups*41; y_pred < 0 is skipped. */
+int cp_confusion(const int32_t* y_pred, const int64_t* labels, int64_t n_groups, int64_t* counts, void* stream);
+
 /* Model.l2() (code/models.py:225-228, 344-349, 467-472) + optimizer_emg.step() +
  * optimizer_glove.step() (code/train.py:72-73, 101, 107-108) over one flat parameter buffer.
  * Tensor table (host arrays, n <= 64): offset/numel into the flat buffers, group (0 emg_net,
