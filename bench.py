@@ -119,6 +119,11 @@ def main():
     if args.gpus != world:
         if args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    # CP_BENCH_REHEARSE=gloo: rehearsal of the multi-rank control flow on a ONE-GPU box (all ranks share cuda:0,
+    # collectives over gloo); timings of such a run mean nothing and the JSON line says so.
+    rehearse = os.environ.get("CP_BENCH_REHEARSE", "")
+    if rehearse:
+        local_rank = min(local_rank, torch.cuda.device_count() - 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -127,7 +132,10 @@ def main():
     use_dist = world > 1 or os.environ.get("CP_BENCH_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(rehearse)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from contrastiveprosthetics_amd.engine import Engine
 
@@ -248,6 +256,8 @@ def main():
                                global_batch_groups=world * B, windows_per_step=world * N,
                                parallelism=f"dp{world}" + (" + z all-gather + flat-gradient all-reduce (RCCL)" if world > 1 else "")),
                    loss=loss, train_acc=correct / N, roofline=roof)
+        if rehearse:
+            rec["rehearsal"] = f"ranks share one GPU over {rehearse}: control-flow check only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, threads=min(16, os.cpu_count() or 1))
             rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
