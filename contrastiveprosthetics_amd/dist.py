@@ -80,3 +80,43 @@ def all_gather_rows(local: torch.Tensor, out: torch.Tensor = None) -> torch.Tens
 def local_rows(gathered: torch.Tensor, n_local: int) -> torch.Tensor:
     r = rank()
     return gathered[r * n_local:(r + 1) * n_local]
+
+
+# ---- hyper-parameter sweep packing ----------------------------------------------
+# The random search of code/train.py:140-166,175-194 trains `--crossval_size` independent models one after the
+# other.  Packed, rank r of w trains configurations r, r+w, r+2w, ... on its own (no gradient exchange), with any
+# number of ranks per GPU: at the reference's batch sizes a training step is launch-latency-bound, so several
+# processes share one MI355X without slowing each other much.  Results travel as Python objects over gloo.
+def init_packed_from_env():
+    """Join RANK / WORLD_SIZE over gloo and return (rank, world, device index = LOCAL_RANK mod visible GPUs)."""
+    w = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    dev = local % n_dev if n_dev else 0
+    if w > 1 and not td.is_initialized():
+        td.init_process_group("gloo")
+    return rank(), world_size(), dev
+
+
+def packed_indices(n_items: int, r: int, w: int):
+    """Round-robin share of rank r: r, r+w, ... (keeps every rank busy when later configurations are the slow ones)."""
+    return list(range(r, n_items, w))
+
+
+def gather_packed(local: dict, n_items: int):
+    """local: {item index: result} of this rank -> list of n_items results on every rank, in item order."""
+    if world_size() == 1:
+        parts = [local]
+    else:
+        parts = [None] * world_size()
+        td.all_gather_object(parts, local)
+    merged = {}
+    for part in parts:
+        for k, v in part.items():
+            if k in merged:
+                raise RuntimeError(f"configuration {k} was trained by two ranks")
+            merged[k] = v
+    missing = [i for i in range(n_items) if i not in merged]
+    if missing:
+        raise RuntimeError(f"configurations {missing} were trained by no rank")
+    return [merged[i] for i in range(n_items)]

@@ -58,14 +58,14 @@ def validate(model, dataset):
 
 
 def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints/model", annealing=False, load=None,
-               verbose=False):
-    """code/train.py:65-138"""
+               verbose=False, solo=False):
+    """code/train.py:65-138.  solo: this process trains the model alone even inside a multi-process job (packed sweep)."""
     model = Model(params=params, train_model=True, adabn=args.no_adabn, prediction=args.prediction, glove=args.glove,
                   device="cuda", dtype=args.dtype).to(torch.float32)
     if load is not None:
         print("Loading model")
         model.load_state_dict(torch.load(load + ".pt", weights_only=True))
-    world, rank = cpdist.world_size(), cpdist.rank()
+    world, rank = (1, 0) if solo else (cpdist.world_size(), cpdist.rank())
     if world > 1:
         cpdist.broadcast_(model.engine.values.flat)
     epochs = params["epochs"]
@@ -129,16 +129,21 @@ def cross_validate(des, hyperparams, dataset, id_, epochs=6, save=True, load=Fal
             return np.load(vpath), np.load(kpath)
         print("no stored search under %s: using the reference's published best row" % data_dir)
         return np.array([[3.2197, 0.2510]]), np.array([BEST_KEY])
-    cross_val = {}
-    for d_e in des:
-        for hypervals in zip(*list(hyperparams.values())):
-            current = {k: v for k, v in zip(list(hyperparams.keys()), hypervals)}
-            print(current)
-            params = {"d_e": d_e, "epochs": epochs}
-            params.update(current)
-            (loss_t, acc_t), _ = train_loop(dataset, params, checkpoint=False, verbose=False, load=load_dir)
-            cross_val[(d_e,) + tuple(hypervals)] = (loss_t, acc_t)
-    values, keys = np.array(list(cross_val.values())), np.array(list(cross_val.keys()))
+    configs = [(d_e,) + tuple(hypervals) for d_e in des for hypervals in zip(*list(hyperparams.values()))]
+    packed = bool(getattr(args, "hpo_pack", False))
+    mine = cpdist.packed_indices(len(configs), cpdist.rank(), cpdist.world_size()) if packed else range(len(configs))
+    done = {}
+    for i in mine:
+        if packed:
+            torch.manual_seed(42 + i)      # a configuration's result must not depend on which rank ran it, or after what
+        current = {k: v for k, v in zip(list(hyperparams.keys()), configs[i][1:])}
+        print(current)
+        params = {"d_e": configs[i][0], "epochs": epochs}
+        params.update(current)
+        (loss_t, acc_t), _ = train_loop(dataset, params, checkpoint=False, verbose=False, load=load_dir, solo=packed)
+        done[i] = (loss_t, acc_t)
+    results = cpdist.gather_packed(done, len(configs)) if packed else [done[i] for i in range(len(configs))]
+    values, keys = np.array(results), np.array(configs)
     if save and cpdist.rank() == 0:
         os.makedirs(data_dir, exist_ok=True)
         np.save(vpath, values)
@@ -149,8 +154,13 @@ def cross_validate(des, hyperparams, dataset, id_, epochs=6, save=True, load=Fal
 def main(a):
     global args
     args = a
-    cpdist.init_from_env()
-    np.random.seed(42)                                   # code/train.py:22
+    if args.hpo_pack:
+        _, _, dev = cpdist.init_packed_from_env()
+        torch.cuda.set_device(dev)
+    else:
+        cpdist.init_from_env()
+    torch.manual_seed(42)                                # code/train.py:21 (torch.cuda.manual_seed(42); seeds the
+    np.random.seed(42)                                   # sampler tables TaskWrapper.reset draws on the GPU), :22
     dataset23 = DB23(db2=args.db2)
     print("Loading dataset")
     if args.synthetic:
@@ -172,6 +182,12 @@ def main(a):
                                   load=args.crossval_load)
     best_key = keys[np.nanargmax(values[:, 1])]
     print("Best combination: %s" % str(best_key))
+    if args.hpo_pack and cpdist.world_size() > 1:
+        # the packed job exists for the search; the final model is trained by rank 0 alone
+        if cpdist.rank() != 0:
+            cpdist.shutdown()
+            return
+    solo_final = bool(args.hpo_pack)
     d_e, lr_e, reg_e, dp_e, lr_g, reg_g, dp_g = best_key
     k = 1 / 10 if args.load_model else 1
     params = {"d_e": int(d_e), "epochs": args.final_epochs, "lr_emg": lr_e * k, "dp_emg": dp_e, "reg_emg": reg_e,
@@ -179,7 +195,7 @@ def main(a):
     checkpoint_dir = os.path.join(args.checkpoint_dir, "contrastive")
     final_vals, model = train_loop(dataset23, params, checkpoint=args.no_checkpoint, annealing=True,
                                    checkpoint_dir=checkpoint_dir, verbose=args.no_verbose,
-                                   load=checkpoint_dir if args.load_model else None)
+                                   load=checkpoint_dir if args.load_model else None, solo=solo_final)
     print("Final validation model statistics")
     print(final_vals)
     if os.path.exists(checkpoint_dir + ".pt"):
@@ -211,6 +227,9 @@ def build_parser():
     parser.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="activation storage / MFMA input type")
     parser.add_argument("--data_dir", default="../data")
     parser.add_argument("--checkpoint_dir", default="../checkpoints")
+    parser.add_argument("--hpo_pack", action="store_true",
+                        help="packed random search: every rank trains its share of the --crossval_size configurations alone "
+                             "(any number of ranks per GPU, results gathered over gloo); rank 0 then trains the final model")
     return parser
 
 
