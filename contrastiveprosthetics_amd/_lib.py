@@ -59,6 +59,10 @@ SYMBOLS = {
     "cp_vote": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp]),
     "cp_subset_vote": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, _fp, _fp]),
     "cp_confusion": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp]),
+    "cp_preprocess_emg": (C.c_int, [_fp, C.c_int64, C.c_int32, _P(C.c_double), _P(C.c_double), C.c_int32, C.c_int32, C.c_float,
+                                    _P(C.c_int32), C.c_int32, _fp, _fp]),
+    "cp_emg_stats": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp]),
+    "cp_emg_normalize": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
     "cp_optimizer_scratch_floats": (C.c_size_t, [_P(C.c_int64), C.c_int32]),
     "cp_l2_norms": (C.c_int, [_fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32), C.c_int32,
                               _P(cp_adam_hyper), _fp, _fp, _fp]),

@@ -18,6 +18,7 @@
 #include "head.cuh"
 #include "optim.cuh"
 #include "eval.cuh"
+#include "preprocess.cuh"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* what) {
@@ -458,6 +459,57 @@ extern "C" int cp_confusion(const int32_t* y_pred, const int64_t* labels, int64_
     const int g = (int)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
     hipLaunchKernelGGL(confusion_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, y_pred, labels, n, (unsigned long long*)counts);
     CKL("confusion_kernel");
+    return 0;
+}
+
+extern "C" int cp_preprocess_emg(const float* raw, int64_t n_segments, int32_t seg_len, const double* b, const double* a,
+                                 int32_t n_coef, int32_t rms_window, float gain, const int32_t* time_idx, int32_t n_out,
+                                 float* out, void* stream) {
+    if (!raw || !b || !a || !time_idx || !out || n_segments <= 0 || n_coef < 2 || n_coef > PP_MAXCOEF || a[0] == 0.0 ||
+        rms_window < 1 || rms_window > PP_MAXWIN || n_out <= 0 || n_out > PP_MAXOUT || seg_len < rms_window)
+        return fail(CP_ERR_ARG, "cp_preprocess_emg args");
+    PreprocArgs p{};
+    p.raw = raw; p.out = out; p.S = n_segments; p.L = seg_len; p.n_out = n_out; p.n_coef = n_coef; p.win = rms_window; p.gain = gain;
+    for (int i = 0; i < n_coef; ++i) { p.b[i] = b[i] / a[0]; p.a[i] = a[i] / a[0]; }
+    const int half = rms_window / 2, n_rms = seg_len - 2 * half;
+    // keep list sorted by time (stable), so a thread walks it once while the series streams by
+    int order[PP_MAXOUT];
+    for (int i = 0; i < n_out; ++i) {
+        if (time_idx[i] < 0 || time_idx[i] >= n_rms) return fail(CP_ERR_ARG, "cp_preprocess_emg: time_idx outside the RMS series");
+        order[i] = i;
+    }
+    for (int i = 1; i < n_out; ++i) {
+        const int v = order[i];
+        int k = i - 1;
+        while (k >= 0 && time_idx[order[k]] > time_idx[v]) { order[k + 1] = order[k]; --k; }
+        order[k + 1] = v;
+    }
+    for (int i = 0; i < n_out; ++i) { p.t_sorted[i] = (short)time_idx[order[i]]; p.slot_sorted[i] = (short)order[i]; }
+    const int64_t threads = n_segments * PP_C;
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (n_coef == 9 && rms_window == 11) hipLaunchKernelGGL((preprocess_kernel<9, 11>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((preprocess_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    CKL("preprocess_kernel");
+    return 0;
+}
+
+extern "C" int cp_emg_stats(const float* seg, int64_t n_segments, int32_t n_out, const uint8_t* use, int32_t complete,
+                            double* scratch, float* mean_std, void* stream) {
+    if (!seg || !scratch || !mean_std || n_segments < 2 || n_out <= 0) return fail(CP_ERR_ARG, "cp_emg_stats args");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t threads = n_segments * PP_C;
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, seg, n_segments, (int)n_out, scratch);
+    hipLaunchKernelGGL(emg_stats_kernel, dim3(1), dim3(256), 0, st, scratch, use, n_segments, (int)complete, mean_std);
+    CKL("emg_stats_kernel");
+    return 0;
+}
+
+extern "C" int cp_emg_normalize(float* seg, int64_t n_rows, const float* mean_std, void* stream) {
+    if (!seg || !mean_std || n_rows <= 0) return fail(CP_ERR_ARG, "cp_emg_normalize args");
+    const int64_t n = n_rows * PP_C;
+    const int g = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(emg_normalize_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, seg, n, mean_std);
+    CKL("emg_normalize_kernel");
     return 0;
 }
 

@@ -135,6 +135,28 @@ int cp_subset_vote(const float* logits, const int64_t* labels, int64_t B, int32_
  * counts (41,41) int64 += 1 at [labels[i % 41]][y_pred[i]] for i < n_groups*41; y_pred < 0 is skipped. */
 int cp_confusion(const int32_t* y_pred, const int64_t* labels, int64_t n_groups, int64_t* counts, void* stream);
 
+/* Raw-sEMG preprocessing = DB23.get_stim_rep after the slice (code/load.py:102-109) with
+ * utils.filter / utils.rms (code/utils.py:137-156), for all segments at once.
+ * raw (n_segments, seg_len, 12) f32 on the device: the first seg_len = 2000 + 2*5 samples of each
+ * (stimulus, repetition) mask, as scipy.io.loadmat delivers `emg` (float32).  b, a: HOST pointers to the n_coef <= 17
+ * IIR coefficients (scipy.signal.butter(4, (20, 450)/1000, "bandpass") in the reference); gain = 2**10;
+ * rms_window = 11; time_idx: HOST pointer to the n_out <= 256 kept positions of the RMS series
+ * (load.py:115 time_mask, whose uint8 wraps modulo 256 -- pass what the reference computes).
+ * out (n_segments, n_out, 12) f32.  Rounding points follow NumPy/SciPy exactly: bit-identical samples. */
+int cp_preprocess_emg(const float* raw, int64_t n_segments, int32_t seg_len, const double* b, const double* a,
+                      int32_t n_coef, int32_t rms_window, float gain, const int32_t* time_idx, int32_t n_out,
+                      float* out, void* stream);
+
+/* utils.RunningStats over preprocessed segments (code/utils.py:79-135; load.py:116,141-144): statistics of the
+ * per-segment channel means of the segments with use[s] != 0 (use == NULL: all) -- their mean and sample standard
+ * deviation per channel, or averaged over channels when complete != 0.  scratch: n_segments*12 doubles on the
+ * device.  mean_std (2,12) f32 on the device. */
+int cp_emg_stats(const float* seg, int64_t n_segments, int32_t n_out, const uint8_t* use, int32_t complete,
+                 double* scratch, float* mean_std, void* stream);
+
+/* RunningStats.normalize (code/utils.py:134, load.py:148): seg = (seg - mean) / std in place, f32. */
+int cp_emg_normalize(float* seg, int64_t n_rows, const float* mean_std, void* stream);
+
 /* Model.l2() (code/models.py:225-228, 344-349, 467-472) + optimizer_emg.step() +
  * optimizer_glove.step() (code/train.py:72-73, 101, 107-108) over one flat parameter buffer.
  * Tensor table (host arrays, n <= 64): offset/numel into the flat buffers, group (0 emg_net,
