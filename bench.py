@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--cpu_seconds", type=float, default=15.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel-kind times to stderr")
+    ap.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],
+                    help="glove = BASELINE config 3 (glove-angle class encoder); the default line is config 1 (one-hot)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,7 +144,8 @@ def main():
     B = args.batch_size
     N = B * T
     params = dict(BEST, dp_emg=args.dp_emg)
-    eng = Engine(adabn=args.adabn, dtype=args.dtype, dp_emg=args.dp_emg, device=dev, seed=1000 + rank)
+    eng = Engine(adabn=args.adabn, dtype=args.dtype, dp_emg=args.dp_emg, device=dev, seed=1000 + rank,
+                 class_encoder=args.class_encoder)
     eng.init_parameters(seed=42)                      # identical replicas, as DDP broadcasts them
     eng.workspace(N)
 
@@ -157,6 +160,10 @@ def main():
     perms = [torch.randperm(D, generator=g)[:B].to(dev) for _ in range(total)]
     z_all = torch.empty(world * N, 16, device=dev) if use_dist else None
     state = {}
+    glove_rows = None
+    if args.class_encoder == "glove":          # per-(group, class) glove-angle rows: class mean + within-class spread
+        gm = torch.randn(T, 20, generator=g)
+        glove_rows = (gm[None] + 0.3 * torch.randn(B, T, 20, generator=g)).to(dev)
 
     def step(i):
         x = eng.gather(table, emg_rand, perms[i], 1)
@@ -168,8 +175,14 @@ def main():
             # SURVEY.md 8e), so the collective runs on RCCL's stream BESIDE the backward pass and is only
             # waited for at the end of the step.
             work = dist.all_gather_into_tensor(z_all, z, async_op=True)
-        out, pred, _ = eng.head(z, labels, 1, want_grad=True)
-        eng.encoder_backward(x)
+        if glove_rows is not None:
+            zg = eng.glove_forward(glove_rows, training=True)
+            out, pred, _ = eng.head_glove(z, zg, labels, 1, want_grad=True)
+            eng.encoder_backward(x)
+            eng.glove_backward()
+        else:
+            out, pred, _ = eng.head(z, labels, 1, want_grad=True)
+            eng.encoder_backward(x)
         if use_dist:
             dist.all_reduce(eng.grads.flat)          # one 8 MB sum; averaged by grad_scale inside Adam
         eng.adam_step(params, grad_scale=1.0 / world)
@@ -250,7 +263,7 @@ def main():
                    unit="windows/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=args.dtype, data="synthetic",
-                   config=dict(workload=f"synthetic 12-ch sEMG, 41-class one-hot, batch {B} groups/GPU "
+                   config=dict(workload=f"synthetic 12-ch sEMG, 41-class {'glove-angle (20-dim) class encoder' if glove_rows is not None else 'one-hot'}, batch {B} groups/GPU "
                                         f"({N} windows/GPU/step), {'AdaBN' if args.adabn else 'stock BN (--no_adabn)'}, "
                                         f"dp_emg={args.dp_emg}, d_e=16, random-init weights",
                                global_batch_groups=world * B, windows_per_step=world * N,

@@ -47,6 +47,11 @@ class cp_adam_hyper(C.Structure):
 
 # every symbol include/cpnative.h declares: (restype, argtypes)
 _P = C.POINTER
+class cp_glove_params(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("bn_g", C.c_void_p), ("bn_b", C.c_void_p), ("last_w", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+
+
 SYMBOLS = {
     "cp_version": (C.c_int, []),
     "cp_last_error": (C.c_char_p, []),
@@ -63,6 +68,11 @@ SYMBOLS = {
                                     _P(C.c_int32), C.c_int32, _fp, _fp]),
     "cp_emg_stats": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp]),
     "cp_emg_normalize": (C.c_int, [_fp, C.c_int64, _fp, _fp]),
+    "cp_glove_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "cp_glove_forward": (C.c_int, [_P(cp_config), _P(cp_glove_params), _fp, C.c_int64, _fp, C.c_size_t, _fp, _fp]),
+    "cp_head_glove": (C.c_int, [_P(cp_config), _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp,
+                                C.c_size_t, _fp, _fp, _fp, _fp]),
+    "cp_glove_backward": (C.c_int, [_P(cp_config), _P(cp_glove_params), C.c_int64, _fp, C.c_size_t, _P(cp_glove_params), _fp]),
     "cp_optimizer_scratch_floats": (C.c_size_t, [_P(C.c_int64), C.c_int32]),
     "cp_l2_norms": (C.c_int, [_fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32), C.c_int32,
                               _P(cp_adam_hyper), _fp, _fp, _fp]),

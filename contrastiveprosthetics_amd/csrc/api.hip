@@ -19,6 +19,7 @@
 #include "optim.cuh"
 #include "eval.cuh"
 #include "preprocess.cuh"
+#include "glove.cuh"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* what) {
@@ -516,6 +517,215 @@ extern "C" int cp_emg_normalize(float* seg, int64_t n_rows, const float* mean_st
 // ---------------------------------------------------------------------------------------
 // encoder backward
 // ---------------------------------------------------------------------------------------
+static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t* rows_per_split);
+
+// ---------------------------------------------------------------------------------------
+// glove-angle class encoder
+// ---------------------------------------------------------------------------------------
+struct GWS {
+    size_t xp, w1p, h, a, w2p, w2t, dzg, gbuf, stats, coef, zeros, partials, partials2, slabs, total;
+};
+static const int kGlovePartialRows = 2048, kGloveSlabs = 128;
+
+static GWS carve_glove(int64_t rows, int dtype) {
+    const size_t es = dtype == CP_BF16 ? 2 : 4;
+    GWS g{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    g.xp = take((size_t)rows * GL_KP * es);
+    g.w1p = take((size_t)GL_H * GL_KP * es);
+    g.h = take((size_t)rows * GL_H * es);
+    g.a = take((size_t)rows * GL_H * es);
+    g.w2p = take((size_t)32 * GL_H * es);
+    g.w2t = take((size_t)GL_H * 64 * es);
+    g.dzg = take((size_t)rows * 64 * es);
+    g.gbuf = take((size_t)rows * GL_H * es);
+    g.stats = take(4 * GL_H * 4);
+    g.coef = take(3 * GL_H * 4);
+    g.zeros = take(GL_H * 4);
+    const int64_t tiles = (rows + 127) / 128;
+    g.partials = take((size_t)(tiles > kGlovePartialRows ? tiles : kGlovePartialRows) * 2 * GL_H * 4);
+    g.partials2 = take((size_t)REDUCE_SLICES * 2048 * 4);
+    g.slabs = take((size_t)kGloveSlabs * 64 * GL_H * 4);
+    g.total = off;
+    return g;
+}
+
+extern "C" size_t cp_glove_workspace_bytes(int64_t max_rows, int32_t dtype) {
+    if (max_rows <= 0 || (dtype != CP_F32 && dtype != CP_BF16)) return 0;
+    return carve_glove(max_rows, dtype).total;
+}
+
+static int check_glove(const cp_config* c, int64_t rows, void* gws, size_t gws_bytes, GWS* out) {
+    if (!c || !gws) return fail(CP_ERR_ARG, "null config/glove workspace");
+    if (rows <= 0 || rows % CP_TASKS != 0) return fail(CP_ERR_ARG, "glove rows must be a positive multiple of 41");
+    if (c->dtype != CP_F32 && c->dtype != CP_BF16) return fail(CP_ERR_ARG, "dtype");
+    *out = carve_glove(rows, c->dtype);
+    if (out->total > gws_bytes) return fail(CP_ERR_WORKSPACE, "glove workspace too small");
+    if (((uintptr_t)gws & 255) != 0) return fail(CP_ERR_ARG, "glove workspace must be 256-byte aligned");
+    return 0;
+}
+
+template <typename T>
+static int glove_forward_t(const cp_config* c, const cp_glove_params* gp, const float* glove, int64_t R, unsigned char* base,
+                           const GWS& w, float* zg, hipStream_t st) {
+    const bool batch_stats = c->training || c->adabn;
+    const bool have_running = gp->running_mean && gp->running_var;
+    if (!batch_stats && !have_running) return fail(CP_ERR_ARG, "eval with stock BN needs running statistics");
+    const int upd = (c->training && !c->adabn && have_running) ? 1 : 0;
+    T* xp = (T*)(base + w.xp);
+    T* h = (T*)(base + w.h);
+    T* av = (T*)(base + w.a);
+    float* partials = (float*)(base + w.partials);
+    float* stats = (float*)(base + w.stats);
+    CK(hipMemsetAsync(base + w.zeros, 0, GL_H * 4, st));
+    hipLaunchKernelGGL((pad_cast_kernel<T>), dim3(grid_rows(R * GL_KP, 256, 4096)), dim3(256), 0, st, glove, R, GL_IN, xp, R, GL_KP);
+    hipLaunchKernelGGL((pad_cast_kernel<T>), dim3(64), dim3(256), 0, st, gp->w1, (int64_t)GL_H, GL_IN, (T*)(base + w.w1p), (int64_t)GL_H, GL_KP);
+    hipLaunchKernelGGL((pad_cast_kernel<T>), dim3(32), dim3(256), 0, st, gp->last_w, (int64_t)CP_D_E, GL_H, (T*)(base + w.w2p), (int64_t)32, GL_H);
+    CKL("pad_cast_kernel");
+    {
+        GemmNTArgs a{};
+        a.A = xp; a.lda = GL_KP; a.M = R; a.K = GL_KP; a.W = base + w.w1p; a.F = GL_H;
+        a.C = h; a.ldc = GL_H; a.bias = (float*)(base + w.zeros); a.relu = 0; a.partials = partials;
+        CK((launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI_FWD>(a, st)));
+    }
+    {
+        int nrows = (int)((R + 127) / 128);
+        const PreReduce pre{partials, (float*)(base + w.partials2), st};
+        const float* pp = batch_stats ? pre(nrows, 2 * GL_H) : partials;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(GL_H / 64), dim3(256), 0, st, pp, nrows, (double)R, gp->bn_g, gp->bn_b,
+                           have_running ? gp->running_mean : nullptr, have_running ? gp->running_var : nullptr, upd,
+                           batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats, GL_H);
+        CKL("bn_finalize_kernel(glove)");
+    }
+    hipLaunchKernelGGL((bn_relu_apply_kernel<T>), dim3(grid_rows(R * GL_H / DT<T>::EPC, 256, 4096)), dim3(256), 0, st, h, stats, av, R, GL_H);
+    CKL("bn_relu_apply_kernel");
+    {
+        GemmNTArgs a{};
+        a.A = av; a.lda = GL_H; a.M = R; a.K = GL_H; a.W = base + w.w2p; a.F = 32;
+        a.C = zg; a.ldc = CP_D_E; a.f_valid = CP_D_E;
+        CK((launch_gemm_nt<T, 128, 32, ALOAD_PLAIN, EPI_PLAIN_F32>(a, st)));
+    }
+    return 0;
+}
+
+extern "C" int cp_glove_forward(const cp_config* cfg, const cp_glove_params* gp, const float* glove, int64_t rows,
+                                void* gws, size_t gws_bytes, float* zg, void* stream) {
+    GWS w;
+    if (int e = check_glove(cfg, rows, gws, gws_bytes, &w)) return e;
+    if (!gp || !gp->w1 || !gp->bn_g || !gp->bn_b || !gp->last_w || !glove || !zg) return fail(CP_ERR_ARG, "cp_glove_forward args");
+    if (cfg->dtype == CP_BF16) return glove_forward_t<bf16_t>(cfg, gp, glove, rows, (unsigned char*)gws, w, zg, (hipStream_t)stream);
+    return glove_forward_t<float>(cfg, gp, glove, rows, (unsigned char*)gws, w, zg, (hipStream_t)stream);
+}
+
+extern "C" int cp_head_glove(const cp_config* cfg, const float* z, const float* zg, const int64_t* labels, int64_t n_groups,
+                             int32_t V, int32_t want_grad, void* ws, size_t ws_bytes, void* gws, size_t gws_bytes,
+                             float* loss_correct, int32_t* pred, float* logits, void* stream) {
+    WS w;
+    if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
+    if (!z || !zg || !labels || !loss_correct || !pred || V <= 0 || n_groups * CP_TASKS != cfg->n_windows || n_groups % V != 0)
+        return fail(CP_ERR_ARG, "cp_head_glove args");
+    if (want_grad && V != 1) return fail(CP_ERR_ARG, "cp_head_glove: gradients need V == 1 (training batches)");
+    const int64_t R = n_groups / V * CP_TASKS;
+    GWS gw;
+    if (int e = check_glove(cfg, R, gws, gws_bytes, &gw)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = (unsigned char*)ws;
+    unsigned char* gbase = (unsigned char*)gws;
+    const size_t es = cfg->dtype == CP_BF16 ? 2 : 4;
+    ProfScope ps(CP_K_HEAD, st);
+    if (want_grad) {
+        CK(hipMemsetAsync(base + w.dz, 0, (size_t)cfg->n_windows * 64 * es, st));
+        CK(hipMemsetAsync(gbase + gw.dzg, 0, (size_t)R * 64 * es, st));
+    }
+    HeadArgs a{};
+    a.z = z; a.labels = labels; a.zg = zg; a.dzg = gbase + gw.dzg; a.dzg_ld = 64;
+    a.G = n_groups; a.V = V; a.want_grad = want_grad; a.dz_ld = 64; a.dz = base + w.dz;
+    a.logits = logits; a.pred = pred; a.partials = (float*)(base + w.head_part);
+    const int blocks = grid_rows(n_groups, HEAD_WAVES, kHeadBlocksMax);
+    if (cfg->dtype == CP_BF16)
+        hipLaunchKernelGGL((head_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((head_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a);
+    CKL("head_kernel<glove>");
+    int nr = blocks;
+    const PreReduce pre{a.partials, (float*)(base + w.partials2), st};
+    const float* pp = pre(nr, HEAD_PART);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, n_groups, (const float*)nullptr, (const float*)nullptr,
+                       0, loss_correct, (float*)nullptr, (float*)nullptr);
+    CKL("head_finalize_kernel");
+    return 0;
+}
+
+template <typename T>
+static int glove_backward_t(const cp_config* c, const cp_glove_params* gp, int64_t R, unsigned char* base, const GWS& w,
+                            cp_glove_params* g, hipStream_t st) {
+    using D = DT<T>;
+    T* xp = (T*)(base + w.xp);
+    T* h = (T*)(base + w.h);
+    T* av = (T*)(base + w.a);
+    T* dzg = (T*)(base + w.dzg);
+    T* gbuf = (T*)(base + w.gbuf);
+    float* partials = (float*)(base + w.partials);
+    float* slabs = (float*)(base + w.slabs);
+    float* stats = (float*)(base + w.stats);
+    float* coef = (float*)(base + w.coef);
+    const PreReduce pre{partials, (float*)(base + w.partials2), st};
+    int S;
+    // last: dW2 = dzg^T a   and   da = dzg W2
+    hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(64), dim3(256), 0, st, gp->last_w, (T*)(base + w.w2t), CP_D_E, GL_H, 64, 0);
+    CKL("transpose_w_kernel(glove)");
+    {
+        GemmTNArgs ta{};
+        ta.X = dzg; ta.ldx = 64; ta.Y = av; ta.ldy = GL_H; ta.slabs = slabs; ta.M = R; ta.P = 64; ta.Q = GL_H;
+        split_rows(R, kGloveSlabs, &S, &ta.rows_per_split);
+        CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, CP_D_E, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, g->last_w, 0, (float*)nullptr);
+        CKL("reduce_slabs(glove last)");
+    }
+    {
+        GemmNTArgs a{};
+        a.A = dzg; a.lda = 64; a.M = R; a.K = 64; a.W = base + w.w2t; a.F = GL_H;
+        a.C = gbuf; a.ldc = GL_H; a.R = nullptr; a.ldr = GL_H; a.partials = partials;
+        CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
+    }
+    // ReLU backward + the BN-backward sums, the coefficients, BN backward
+    {
+        const int gb = grid_rows(R, 256 / (GL_H / D::EPC), kGlovePartialRows);
+        const int rpp = 256 / (GL_H / D::EPC);
+        hipLaunchKernelGGL((relu_bwd_colsum_kernel<T>), dim3(gb), dim3(256), (size_t)rpp * 2 * GL_H * 4, st, gbuf, av, h, partials, R, GL_H);
+        CKL("relu_bwd_colsum_kernel");
+        int nr = gb;
+        const float* pp = pre(nr, 2 * GL_H);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(GL_H / 64), dim3(256), 0, st, pp, nr, (double)R, stats, coef, g->bn_g, g->bn_b, GL_H, 1);
+        CKL("bn_bwd_finalize_kernel(glove)");
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_rows(R * GL_H / D::EPC, 256, 4096)), dim3(256), 0, st, gbuf, h, coef, R, GL_H);
+        CKL("bn_bwd_apply_kernel");
+    }
+    // first Linear: dW1^T = xp^T dh, reduced into the (256,20) layout
+    {
+        GemmTNArgs ta{};
+        ta.X = xp; ta.ldx = GL_KP; ta.Y = gbuf; ta.ldy = GL_H; ta.slabs = slabs; ta.M = R; ta.P = 64; ta.Q = GL_H;
+        split_rows(R, kGloveSlabs, &S, &ta.rows_per_split);
+        CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, GL_IN, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, g->w1, 3, (float*)nullptr);
+        CKL("reduce_slabs(glove w1)");
+    }
+    return 0;
+}
+
+extern "C" int cp_glove_backward(const cp_config* cfg, const cp_glove_params* gp, int64_t rows, void* gws, size_t gws_bytes,
+                                 cp_glove_params* grads, void* stream) {
+    GWS w;
+    if (int e = check_glove(cfg, rows, gws, gws_bytes, &w)) return e;
+    if (!gp || !gp->last_w || !grads || !grads->w1 || !grads->bn_g || !grads->bn_b || !grads->last_w)
+        return fail(CP_ERR_ARG, "cp_glove_backward args");
+    if (cfg->dtype == CP_BF16) return glove_backward_t<bf16_t>(cfg, gp, rows, (unsigned char*)gws, w, grads, (hipStream_t)stream);
+    return glove_backward_t<float>(cfg, gp, rows, (unsigned char*)gws, w, grads, (hipStream_t)stream);
+}
+
 static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t* rows_per_split) {
     int64_t rps = (M + target_splits - 1) / target_splits;
     rps = ((rps + 31) / 32) * 32;

@@ -28,13 +28,20 @@ struct HeadArgs {
     float* logits;           // optional [G][41][41]
     int32_t* pred;           // [G][41]
     float* partials;         // [blocks][HEAD_PART] : loss sum, correct count, dE_hat[41][16]
+    // GLOVE = true: the class embedding of position j of group b is row (b*41 + j) of zg
+    // (the glove-angle encoder's output, one row per (group, class)) instead of row labels[..] of a shared table
+    const float* zg;         // [B*41][16]
+    void* dzg;               // [B*41][dzg_ld] T: dL/dzg through the normalisation (want_grad needs V == 1)
+    int dzg_ld;
 };
 #define HEAD_PART 704        // 2 + 41*16 = 658 used, padded to a multiple of 64 for reduce_rows_kernel
 
-template <typename T>
+template <typename T, bool GLOVE = false>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     using D = DT<T>;
     __shared__ float Eh[HEAD_T][HEAD_D];                 // normalised class table
+    __shared__ float EhW[GLOVE ? HEAD_WAVES : 1][HEAD_T][HEAD_D];   // GLOVE: the group's own normalised class rows
+    __shared__ float EnW[GLOVE ? HEAD_WAVES : 1][HEAD_T + 3];       //        and their norms
     __shared__ float Ls[HEAD_WAVES][HEAD_T][HEAD_T + 2]; // logits / dlogits tile per wave (odd pitch 43)
     __shared__ float Zs[HEAD_WAVES][HEAD_T][HEAD_D];     // z_hat rows per wave
     __shared__ float Cl[HEAD_WAVES][HEAD_T + 3];         // column log-sum-exp per wave
@@ -45,12 +52,14 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < HEAD_T; i += 256) {
-        float e[HEAD_D], n = 0.f;
+        if constexpr (!GLOVE) {
+            float e[HEAD_D], n = 0.f;
 #pragma unroll
-        for (int d = 0; d < HEAD_D; ++d) { e[d] = a.easy_w[d * HEAD_T + i] + a.easy_b[d]; n = fmaf(e[d], e[d], n); }
-        n = sqrtf(n);
+            for (int d = 0; d < HEAD_D; ++d) { e[d] = a.easy_w[d * HEAD_T + i] + a.easy_b[d]; n = fmaf(e[d], e[d], n); }
+            n = sqrtf(n);
 #pragma unroll
-        for (int d = 0; d < HEAD_D; ++d) Eh[i][d] = e[d] / n;
+            for (int d = 0; d < HEAD_D; ++d) Eh[i][d] = e[d] / n;
+        }
         Tg[i] = (int)a.labels[i];
     }
     for (int i = tid; i < HEAD_WAVES * HEAD_T * HEAD_D; i += 256) (&dE[0][0][0])[i] = 0.f;
@@ -66,7 +75,24 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
         const int64_t b = g / a.V;
         const int v = (int)(g % a.V);
         const int64_t zrow = (b * HEAD_T + li) * a.V + v;
-        if (act) Cls[wave][lane] = (int)a.labels[b * HEAD_T + lane];
+        if (act) Cls[wave][lane] = GLOVE ? lane : (int)a.labels[b * HEAD_T + lane];
+        if constexpr (GLOVE) {
+            if (act) {
+                const float4* gp = (const float4*)(a.zg + (b * HEAD_T + lane) * HEAD_D);
+                float e[HEAD_D], n = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t4 = gp[q];
+                    e[4 * q] = t4.x; e[4 * q + 1] = t4.y; e[4 * q + 2] = t4.z; e[4 * q + 3] = t4.w;
+                }
+#pragma unroll
+                for (int d = 0; d < HEAD_D; ++d) n = fmaf(e[d], e[d], n);
+                n = sqrtf(n);
+#pragma unroll
+                for (int d = 0; d < HEAD_D; ++d) EhW[wave][lane][d] = e[d] / n;
+                EnW[wave][lane] = n;
+            }
+        }
         float zh[HEAD_D], nz = 0.f;
         {
             const float4* zp = (const float4*)(a.z + zrow * HEAD_D);
@@ -93,7 +119,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
         int arg = 0;
 #pragma unroll 4
         for (int j = 0; j < HEAD_T; ++j) {
-            const float* e = Eh[Cls[wave][j]];
+            const float* e = GLOVE ? EhW[wave][j] : Eh[Cls[wave][j]];
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < HEAD_D; ++d) s = fmaf(zh[d], e[d], s);
@@ -144,7 +170,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
                 dl -= (j == tgt) ? 1.f : 0.f;
                 dl -= (Tg[j] == li) ? 1.f : 0.f;
                 dl *= cscale;
-                const float* e = Eh[Cls[wave][j]];
+                const float* e = GLOVE ? EhW[wave][j] : Eh[Cls[wave][j]];
 #pragma unroll
                 for (int d = 0; d < HEAD_D; ++d) dzh[d] = fmaf(dl, e[d], dzh[d]);
                 if (act) Ls[wave][lane][j] = dl;      // own row, read above: the tile now holds dlogits
@@ -174,9 +200,22 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
 #pragma unroll
                     for (int d = 0; d < HEAD_D; ++d) accd[d] = fmaf(dl, Zs[wave][i][d], accd[d]);
                 }
-                const int c = Cls[wave][lane];
+                if constexpr (GLOVE) {
+                    // position j's embedding belongs to this group alone: through its normalisation, straight out
+                    float dot = 0.f;
 #pragma unroll
-                for (int d = 0; d < HEAD_D; ++d) atomicAdd(&dE[wave][c][d], accd[d]);
+                    for (int d = 0; d < HEAD_D; ++d) dot = fmaf(EhW[wave][lane][d], accd[d], dot);
+                    float o[HEAD_D];
+#pragma unroll
+                    for (int d = 0; d < HEAD_D; ++d) o[d] = (accd[d] - EhW[wave][lane][d] * dot) / EnW[wave][lane];
+                    T* dst = (T*)a.dzg + (b * HEAD_T + lane) * a.dzg_ld;
+#pragma unroll
+                    for (int c = 0; c < HEAD_D / D::EPC; ++c) *(uint4*)(dst + c * D::EPC) = D::pack(o + c * D::EPC);
+                } else {
+                    const int c = Cls[wave][lane];
+#pragma unroll
+                    for (int d = 0; d < HEAD_D; ++d) atomicAdd(&dE[wave][c][d], accd[d]);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }

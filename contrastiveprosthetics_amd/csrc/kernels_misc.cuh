@@ -323,6 +323,7 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ partials, in
 //   mode 0 (fc):   grad[p*Q + q]      = s[q]*P + t[q]*dbsum[p]
 //   mode 1 (fc1):  q = w*64 + c  ->   grad[p*768 + c*12 + w] = s[c]*P + t[c]*dbsum[p]
 //   mode 2 (conv2): q = tap*64 + i -> grad[((p*64+i)*3+1)*3+tap] = P  (+ zero the dead kernel rows)
+//   mode 3 (transposed): grad[q*p_valid + p] = P   (slab rows are the operand that was padded)
 //   rows p >= p_valid are dropped (projection padded 16 -> 64)
 // ------------------------------------------------------------------------------------
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int P, int Q, int p_valid,
@@ -355,6 +356,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
         } else {
             int ch = q, dst = p * Q + q;
             if (mode == 1) { ch = q & 63; dst = p * Q + ch * 12 + (q >> 6); }
+            if (mode == 3) dst = q * p_valid + p;
             if (s != nullptr) acc = fmaf(s[ch], acc, t[ch] * dbsum[p]);
             grad[dst] = acc;
         }

@@ -28,8 +28,18 @@ def bn_bases(adabn: bool):
             + [f"emg_net.linear.{i}{sfx}" for i in LINEAR_BN_IDX])
 
 
-def param_specs(adabn: bool, d_e: int = CP_D_E) -> "OrderedDict[str, Tuple[int, ...]]":
-    """Trainable tensors in reference state_dict order, without logit_scale."""
+GLOVE_DIM, GLOVE_HIDDEN = 20, 256
+GLOVE_LINEAR_KEY = "glove_net.linear.1.weight"        # Sequential(Flatten, Linear, BN, ReLU): the Linear is index 1
+
+
+def glove_bn_base(adabn: bool) -> str:
+    return "glove_net.linear.2" + (".bn" if adabn else "")
+
+
+def param_specs(adabn: bool, d_e: int = CP_D_E, class_encoder: str = "onehot") -> "OrderedDict[str, Tuple[int, ...]]":
+    """Trainable tensors in reference state_dict order, without logit_scale.
+    class_encoder="glove" adds the layers GLOVENet keeps as comments (code/models.py:386-391), where
+    nn.Module.state_dict() would list them: glove_net.linear.* before glove_net.easy.*."""
     bn = bn_bases(adabn)
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     s["emg_net.conv_emg.0.weight"] = (64, 1, 3, 3)
@@ -48,6 +58,10 @@ def param_specs(adabn: bool, d_e: int = CP_D_E) -> "OrderedDict[str, Tuple[int, 
         s[bn[2 + n] + ".bias"] = (512,)
         k = 512
     s["emg_net.last.0.weight"] = (d_e, 512)
+    if class_encoder == "glove":
+        s[GLOVE_LINEAR_KEY] = (GLOVE_HIDDEN, GLOVE_DIM)
+        s[glove_bn_base(adabn) + ".weight"] = (GLOVE_HIDDEN,)
+        s[glove_bn_base(adabn) + ".bias"] = (GLOVE_HIDDEN,)
     s["glove_net.easy.0.weight"] = (d_e, CP_TASKS)
     s["glove_net.easy.0.bias"] = (d_e,)
     s["glove_net.last.0.weight"] = (d_e, 256)
@@ -146,7 +160,10 @@ def confusion(y_pred: torch.Tensor, labels: torch.Tensor, counts: torch.Tensor =
 
 class Engine:
     def __init__(self, adabn: bool = True, dtype: str = "bf16", dp_emg: float = 0.0, device="cuda",
-                 d_e: int = CP_D_E, seed: int = 0):
+                 d_e: int = CP_D_E, seed: int = 0, class_encoder: str = "onehot"):
+        if class_encoder not in ("onehot", "glove"):
+            raise ValueError("class_encoder must be 'onehot' or 'glove'")
+        self.class_encoder = class_encoder
         if d_e != CP_D_E:
             raise ValueError(f"the HIP head kernel is built for d_e={CP_D_E} (code/train.py:183), got {d_e}")
         if dtype not in ("f32", "bf16"):
@@ -160,7 +177,7 @@ class Engine:
         self.dp_emg = float(dp_emg)
         self.seed = int(seed)
         self.step_count = 0              # forward passes in train mode (dropout stream)
-        self.specs = param_specs(self.adabn, d_e)
+        self.specs = param_specs(self.adabn, d_e, class_encoder)
         self.values = FlatStore(self.specs, self.device)
         self.grads = FlatStore(self.specs, self.device)
         self.exp_avg = torch.zeros_like(self.values.flat)
@@ -169,7 +186,7 @@ class Engine:
         self.num_batches_tracked = 0
         self.running: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         if not self.adabn:
-            for b in bn_bases(False):
+            for b in bn_bases(False) + ([glove_bn_base(False)] if class_encoder == "glove" else []):
                 n = self.specs[b + ".weight"][0]
                 self.running[b + ".running_mean"] = torch.zeros(n, device=self.device)
                 self.running[b + ".running_var"] = torch.ones(n, device=self.device)
@@ -181,6 +198,20 @@ class Engine:
             for n, b in enumerate(bn_bases(False)):
                 self._bn.running_mean[n] = self.running[b + ".running_mean"].data_ptr()
                 self._bn.running_var[n] = self.running[b + ".running_var"].data_ptr()
+        self._gp = self._gg = None
+        if class_encoder == "glove":
+            self._gp, self._gg = _lib.cp_glove_params(), _lib.cp_glove_params()
+            gb = glove_bn_base(self.adabn)
+            for st, store in ((self._gp, self.values), (self._gg, self.grads)):
+                st.w1 = store.views[GLOVE_LINEAR_KEY].data_ptr()
+                st.bn_g = store.views[gb + ".weight"].data_ptr()
+                st.bn_b = store.views[gb + ".bias"].data_ptr()
+                st.last_w = store.views["glove_net.last.0.weight"].data_ptr()
+            if not self.adabn:
+                self._gp.running_mean = self.running[gb + ".running_mean"].data_ptr()
+                self._gp.running_var = self.running[gb + ".running_var"].data_ptr()
+        self._gws: Optional[torch.Tensor] = None
+        self._gws_rows = 0
         self._ws: Optional[torch.Tensor] = None
         self._ws_windows = 0
         names = list(self.specs)
@@ -270,6 +301,52 @@ class Engine:
                                     logits.data_ptr() if want_logits else None, C.byref(self._g), self._stream()),
                    "cp_head")
         return out, pred, logits
+
+    # ------------------------------------------------------------------ glove-angle class encoder (row f2)
+    def _gws_args(self, rows: int):
+        if self._gws is None or rows > self._gws_rows:
+            self._gws = None
+            self._gws = torch.empty(self.lib.cp_glove_workspace_bytes(rows, self.dtype), dtype=torch.uint8, device=self.device)
+            self._gws_rows = rows
+        # as with the main workspace the carve depends on `rows`: the buffer may be larger, never smaller
+        return self._gws.data_ptr(), self._gws.numel()
+
+    def glove_forward(self, glove: torch.Tensor, training: bool) -> torch.Tensor:
+        """GLOVENet.forward, glove branch: glove (B,41,20) -> zg (B*41,16) f32."""
+        if self._gp is None:
+            raise _lib.CpNativeError("Engine was built with class_encoder='onehot'")
+        x = glove.reshape(-1, GLOVE_DIM).to(torch.float32).contiguous()
+        rows = x.shape[0]
+        cfg = self._cfg(rows, training)
+        zg = torch.empty(rows, CP_D_E, dtype=torch.float32, device=self.device)
+        gws, nb = self._gws_args(rows)
+        _lib.check(self.lib.cp_glove_forward(C.byref(cfg), C.byref(self._gp), x.data_ptr(), rows, gws, nb, zg.data_ptr(),
+                                             self._stream()), "cp_glove_forward")
+        self._last_glove_rows = rows
+        return zg
+
+    def head_glove(self, z: torch.Tensor, zg: torch.Tensor, labels: torch.Tensor, V: int, want_grad: bool,
+                   want_logits: bool = False):
+        n = z.shape[0]
+        G = n // CP_TASKS
+        assert labels.dtype == torch.int64 and labels.numel() * V == n and zg.shape[0] * V == n
+        cfg = self._cfg(n, self._last[1])
+        out = torch.empty(2, dtype=torch.float32, device=self.device)
+        pred = torch.empty(G, CP_TASKS, dtype=torch.int32, device=self.device)
+        logits = torch.empty(G, CP_TASKS, CP_TASKS, dtype=torch.float32, device=self.device) if want_logits else None
+        ws, nb = self._ws_args(n)
+        gws, gnb = self._gws_args(zg.shape[0])
+        _lib.check(self.lib.cp_head_glove(C.byref(cfg), z.data_ptr(), zg.data_ptr(), labels.data_ptr(), G, V,
+                                          1 if want_grad else 0, ws, nb, gws, gnb, out.data_ptr(), pred.data_ptr(),
+                                          logits.data_ptr() if want_logits else None, self._stream()), "cp_head_glove")
+        return out, pred, logits
+
+    def glove_backward(self):
+        rows = self._last_glove_rows
+        cfg = self._cfg(rows, True)
+        gws, nb = self._gws_args(rows)
+        _lib.check(self.lib.cp_glove_backward(C.byref(cfg), C.byref(self._gp), rows, gws, nb, C.byref(self._gg),
+                                              self._stream()), "cp_glove_backward")
 
     def encoder_backward(self, x: torch.Tensor):
         x = x.reshape(-1, 12)
@@ -362,7 +439,7 @@ class Engine:
         """PyTorch-default initialisation of code/models.py:67-85 (kaiming-uniform a=sqrt(5), i.e.
         U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases; BN gamma 1, beta 0)."""
         g = torch.Generator().manual_seed(seed)
-        bns = set(bn_bases(self.adabn))
+        bns = set(bn_bases(self.adabn)) | {glove_bn_base(self.adabn)}
         for k, shp in self.specs.items():
             base = k.rsplit(".", 1)[0]
             if base in bns:

@@ -105,7 +105,10 @@ class _L2Fn(torch.autograd.Function):
 
 class Model(nn.Module):
     def __init__(self, params, adabn=True, train_model=True, prediction=False, glove=False, device="cuda",
-                 dtype: str = "f32", seed: int = 42):
+                 dtype: str = "f32", seed: int = 42, class_encoder: str = "onehot"):
+        """class_encoder="glove" (additive): class embeddings come from the glove-angle rows that
+        TaskWrapper already delivers, through the layers GLOVENet keeps as comments (code/models.py:386-391, 461),
+        instead of the one-hot table.  (The reference's own `glove` flag belongs to its --prediction classifier.)"""
         super().__init__()
         if prediction or glove:
             raise NotImplementedError("only the contrastive mode (prediction=False, glove=False) is accelerated; "
@@ -116,8 +119,9 @@ class Model(nn.Module):
         self.prediction = prediction
         self.glove = glove
         self.device = torch.device(device)
+        self.class_encoder = class_encoder
         self.engine = Engine(adabn=adabn, dtype=dtype, dp_emg=float(params.get("dp_emg", 0.0)), device=device,
-                             d_e=int(params["d_e"]), seed=seed)
+                             d_e=int(params["d_e"]), seed=seed, class_encoder=class_encoder)
         self.engine.init_parameters(seed)
         self.emg_net = EMGNet()
         self.glove_net = GLOVENet()
@@ -184,7 +188,13 @@ class Model(nn.Module):
         labels = labels.reshape(-1).to(torch.long)
         want_grad = self.training and torch.is_grad_enabled()
         z = self.engine.encoder_forward(x, training=self.training)
-        out, pred, logits = self.engine.head(z, labels, V, want_grad=want_grad, want_logits=True)
+        if self.class_encoder == "glove":
+            if GLOVE is None or tuple(GLOVE.shape[:2]) != (B, T):
+                raise ValueError("class_encoder='glove' needs the (B,41,20) glove tensor TaskWrapper delivers")
+            zg = self.engine.glove_forward(GLOVE, training=self.training)
+            out, pred, logits = self.engine.head_glove(z, zg, labels, V, want_grad=want_grad, want_logits=True)
+        else:
+            out, pred, logits = self.engine.head(z, labels, V, want_grad=want_grad, want_logits=True)
         self._pending = dict(x=x, out=out, pred=pred, labels=labels, B=B, V=V, T=T, want_grad=want_grad, done=False)
         self._last_logits = logits
         return logits
@@ -225,6 +235,8 @@ class Model(nn.Module):
             raise RuntimeError("backward without a training-mode forward")
         if not st["done"]:
             self.engine.encoder_backward(st["x"])
+            if self.class_encoder == "glove":
+                self.engine.glove_backward()
             st["done"] = True
 
     # -- fused step API ------------------------------------------------------------------------------

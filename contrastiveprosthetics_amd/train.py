@@ -61,7 +61,7 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
                verbose=False, solo=False):
     """code/train.py:65-138.  solo: this process trains the model alone even inside a multi-process job (packed sweep)."""
     model = Model(params=params, train_model=True, adabn=args.no_adabn, prediction=args.prediction, glove=args.glove,
-                  device="cuda", dtype=args.dtype).to(torch.float32)
+                  device="cuda", dtype=args.dtype, class_encoder=getattr(args, "class_encoder", "onehot")).to(torch.float32)
     if load is not None:
         print("Loading model")
         model.load_state_dict(torch.load(load + ".pt", weights_only=True))
@@ -227,6 +227,8 @@ def build_parser():
     parser.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="activation storage / MFMA input type")
     parser.add_argument("--data_dir", default="../data")
     parser.add_argument("--checkpoint_dir", default="../checkpoints")
+    parser.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],
+                        help="glove: class embeddings from the glove-angle rows (zero-shot path, BASELINE config 3)")
     parser.add_argument("--hpo_pack", action="store_true",
                         help="packed random search: every rank trains its share of the --crossval_size configurations alone "
                              "(any number of ranks per GPU, results gathered over gloo); rank 0 then trains the final model")

@@ -157,6 +157,37 @@ int cp_emg_stats(const float* seg, int64_t n_segments, int32_t n_out, const uint
 /* RunningStats.normalize (code/utils.py:134, load.py:148): seg = (seg - mean) / std in place, f32. */
 int cp_emg_normalize(float* seg, int64_t n_rows, const float* mean_std, void* stream);
 
+/* ---- glove-angle class encoder (BASELINE config 3) -------------------------------------
+ * zg = last(relu(BN(Linear(20->256, no bias)(glove)))), last = Linear(256->16, no bias): the layers the reference
+ * keeps as comments in GLOVENet (code/models.py:386-391, 461) plus its built-but-unused `self.last`
+ * (code/models.py:425-428).  One row per (group, class).  The contrastive head then takes row (b*41 + j) of zg as
+ * the class embedding of position j of group b, instead of the one-hot table's row labels[b*41 + j]. */
+typedef struct cp_glove_params {
+    float* w1;            /* glove_net.linear.1.weight        (256,20) */
+    float* bn_g;          /* glove_net.linear.2[.bn].weight   (256) */
+    float* bn_b;          /* glove_net.linear.2[.bn].bias     (256) */
+    float* last_w;        /* glove_net.last.0.weight          (16,256) */
+    float* running_mean;  /* stock BN buffers (NULL under AdaBN; unused in a gradient struct) */
+    float* running_var;
+} cp_glove_params;
+
+size_t cp_glove_workspace_bytes(int64_t max_rows, int32_t dtype);
+
+/* GLOVENet.forward, glove branch.  glove (rows,20) f32, rows = B*41; zg (rows,16) f32.  cfg supplies dtype, adabn,
+ * training, bn_momentum, bn_eps (n_windows and the dropout fields are not used).  Saves what backward needs in gws. */
+int cp_glove_forward(const cp_config* cfg, const cp_glove_params* gp, const float* glove, int64_t rows,
+                     void* gws, size_t gws_bytes, float* zg, void* stream);
+
+/* cp_head with per-group class embeddings: same outputs; want_grad (V must be 1) leaves dL/dz in ws for
+ * cp_encoder_backward and dL/dzg in gws for cp_glove_backward. */
+int cp_head_glove(const cp_config* cfg, const float* z, const float* zg, const int64_t* labels, int64_t n_groups,
+                  int32_t V, int32_t want_grad, void* ws, size_t ws_bytes, void* gws, size_t gws_bytes,
+                  float* loss_correct, int32_t* pred, float* logits, void* stream);
+
+/* autograd of the glove encoder: consumes dL/dzg left in gws, writes w1, bn_g, bn_b, last_w of `grads`. */
+int cp_glove_backward(const cp_config* cfg, const cp_glove_params* gp, int64_t rows, void* gws, size_t gws_bytes,
+                      cp_glove_params* grads, void* stream);
+
 /* Model.l2() (code/models.py:225-228, 344-349, 467-472) + optimizer_emg.step() +
  * optimizer_glove.step() (code/train.py:72-73, 101, 107-108) over one flat parameter buffer.
  * Tensor table (host arrays, n <= 64): offset/numel into the flat buffers, group (0 emg_net,

@@ -99,6 +99,43 @@ def param_specs(d_e: int = 16, adabn: bool = False) -> "OrderedDict[str, Tuple[i
     return s
 
 
+# ---- glove-angle class encoder (BASELINE config 3) -- PARITY UNPINNED ------------------
+# The reference holds this encoder only as commented-out lines: `nn.Linear(GLOVE_DIM, 512//2, bias=False)`,
+# `self.bn1d_func(512//2)`, `nn.ReLU()` inside GLOVENet.linear (code/models.py:388-390, after the Flatten at
+# index 0) and `out=self.last(self.linear(out))` in GLOVENet.forward (code/models.py:461), with `self.last` =
+# `nn.Linear(512//2, d_e, bias=False)` (code/models.py:425-428), which IS built and sits unused in every
+# state_dict.  Nothing in the reference can run it, so there are no vectors to pin it to: this restatement
+# un-comments those lines and is the definition the HIP path is checked against.
+GLOVE_HIDDEN = 256
+GLOVE_LINEAR_KEY = "glove_net.linear.1.weight"          # Sequential(Flatten, Linear, BN, ReLU): Linear is index 1
+
+
+def glove_bn_base(adabn: bool) -> str:
+    return _bn_prefix("glove_net.linear.2", adabn)
+
+
+def add_glove_encoder(sd: "OrderedDict[str, torch.Tensor]", seed: int, adabn: bool) -> "OrderedDict[str, torch.Tensor]":
+    """state_dict of the one-hot model -> state_dict with the glove encoder's tensors inserted where
+    nn.Module.state_dict() would put them (glove_net.linear.* before glove_net.easy.*)."""
+    g = torch.Generator().manual_seed(seed)
+    bound = 1.0 / math.sqrt(GLOVE_DIM)
+    extra: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    extra[GLOVE_LINEAR_KEY] = (torch.rand((GLOVE_HIDDEN, GLOVE_DIM), generator=g) * 2 - 1) * bound
+    b = glove_bn_base(adabn)
+    extra[b + ".weight"] = torch.ones(GLOVE_HIDDEN)
+    extra[b + ".bias"] = torch.zeros(GLOVE_HIDDEN)
+    if not adabn:
+        extra[b + ".running_mean"] = torch.zeros(GLOVE_HIDDEN)
+        extra[b + ".running_var"] = torch.ones(GLOVE_HIDDEN)
+        extra[b + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, v in sd.items():
+        if k == "glove_net.easy.0.weight":
+            out.update(extra)
+        out[k] = v
+    return out
+
+
 def bn_bases(adabn: bool) -> List[str]:
     return ([_bn_prefix("emg_net.conv_emg.2", adabn), _bn_prefix("emg_net.conv_emg.5", adabn)]
             + [_bn_prefix(f"emg_net.linear.{bi}", adabn) for bi in LINEAR_BN_IDX])
@@ -148,7 +185,8 @@ def trainable_keys(sd: Dict[str, torch.Tensor]) -> Tuple[List[str], List[str]]:
     ``logit_scale`` belongs to neither."""
     emg = [k for k, v in sd.items() if k.startswith("emg_net.") and v.dtype.is_floating_point
            and not k.endswith(("running_mean", "running_var"))]
-    glove = [k for k, v in sd.items() if k.startswith("glove_net.") and v.dtype.is_floating_point]
+    glove = [k for k, v in sd.items() if k.startswith("glove_net.") and v.dtype.is_floating_point
+             and not k.endswith(("running_mean", "running_var"))]
     return emg, glove
 
 
@@ -160,8 +198,9 @@ class OracleModel:
     (code/models.py:66-228, 230-349, 352-472), contrastive mode only."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], params: Dict[str, float],
-                 adabn: bool = False, requires_grad: bool = False):
+                 adabn: bool = False, requires_grad: bool = False, class_encoder: str = "onehot"):
         self.adabn = adabn
+        self.class_encoder = class_encoder           # "onehot" (the reference as it runs) | "glove" (row f2, unpinned)
         self.params = dict(params)
         self.sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         for k, v in state_dict.items():
@@ -255,10 +294,19 @@ class OracleModel:
         return out.reshape(-1, shape[1], d_e)
 
     # -- class encoder, contrastive branch (models.py:447-465, 412-414) ------
-    def encode_class(self, GLOVE: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    def encode_class(self, GLOVE: torch.Tensor, labels: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         sd = self.sd
-        hot = F.one_hot(labels).to(sd["glove_net.easy.0.weight"].dtype)
-        out = F.linear(hot, sd["glove_net.easy.0.weight"], sd["glove_net.easy.0.bias"])
+        if self.class_encoder == "glove":
+            # code/models.py:386-391,461 un-commented: Flatten -> Linear(20,256,no bias) -> BN -> ReLU -> last
+            x = GLOVE.reshape(-1, GLOVE_DIM).to(sd[GLOVE_LINEAR_KEY].dtype)
+            h = F.linear(x, sd[GLOVE_LINEAR_KEY])
+            a = F.relu(self._bn(h, glove_bn_base(self.adabn)))
+            out = F.linear(a, sd["glove_net.last.0.weight"])
+            if taps is not None:
+                taps["glove_h"], taps["glove_a"], taps["zg"] = h, a, out
+        else:
+            hot = F.one_hot(labels).to(sd["glove_net.easy.0.weight"].dtype)
+            out = F.linear(hot, sd["glove_net.easy.0.weight"], sd["glove_net.easy.0.bias"])
         B, T = GLOVE.shape[0], GLOVE.shape[1]
         d_e = out.shape[-1]
         out = out.reshape(B, -1, d_e)
@@ -272,7 +320,7 @@ class OracleModel:
                 relu_masks: Optional[dict] = None) -> torch.Tensor:
         ze = self.encode_emg(EMG, taps, dropout_masks, relu_masks)
         ze = ze / ze.norm(dim=-1, keepdim=True)
-        zc = self.encode_class(GLOVE, labels)
+        zc = self.encode_class(GLOVE, labels, taps)
         zc = zc / zc.norm(dim=-1, keepdim=True)
         return torch.bmm(ze, zc.transpose(1, 2))
 
