@@ -37,8 +37,8 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 # profiler kind -> (the ONE kernel it times, as rocprofv3 names it; fc layer indices it runs on when dropout is on / off)
 GEMM_KERNELS = {
     "fc_fwd": "gemm_nt256p_kernel<0, 4>",          # persistent, bias + ReLU + BN sums in the epilogue
-    "fc_dgrad": "gemm_nt256p_kernel<1, 4>",        # persistent, plain data gradient
-    "fc_dgrad_stats": "gemm_nt256_kernel<1>",      # dropout on the input: dropout mask + BN-backward sums vs the saved activation
+    "fc_dgrad": "gemm_nt256p_kernel<1, 4>",        # persistent, plain data gradient (unfused mode only)
+    "fc_dgrad_stats": "gemm_nt256_kernel<1>",      # data gradient whose epilogue works against the saved activation
     "fc_wgrad": "gemm_tn256_kernel",
 }
 
@@ -52,10 +52,13 @@ def gemm_model(kind: str, n: int, es: int, dropout: bool):
     ks = [768] + [512] * 6
     if kind == "fc_fwd":            # read input, write post-ReLU output
         layers, per = range(7), lambda k: k + 512
-    elif kind == "fc_dgrad":        # read g_y, write g_v
-        layers, per = (range(4) if dropout else range(7)), lambda k: 512 + k
-    elif kind == "fc_dgrad_stats":  # read g_y and the saved activation, write g_v
-        layers, per = (range(4, 7) if dropout else range(0)), lambda k: 512 + 2 * k
+    elif kind == "fc_dgrad":        # read g_y, write g_v (only with CPNATIVE_UNFUSED_BN_BWD: the plain persistent launch)
+        unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD"))
+        layers, per = ((range(4) if dropout else range(7)) if unfused else range(0)), lambda k: 512 + k
+    elif kind == "fc_dgrad_stats":  # read g_y and the saved activation, write g_v: behind a dropout the epilogue reduces
+        #                             the BN-backward sums against it, elsewhere it applies BN + ReLU backward with it
+        unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD"))
+        layers, per = ((range(4, 7) if dropout else range(0)) if unfused else range(7)), lambda k: 512 + 2 * k
     else:                           # fc_wgrad: read g_y and the layer input
         layers, per = range(7), lambda k: 512 + k
     layers = list(layers)

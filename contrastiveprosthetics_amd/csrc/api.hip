@@ -801,9 +801,16 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
     }
     // ---- fc7 .. fc1 --------------------------------------------------------------------
+    // bn_done: BatchNorm + ReLU backward of layer L were applied by the data-gradient launch of the layer above (its
+    // staged epilogue, GemmNTArgs::coef), so `cur` already is dL/d(pre-activation) and the bias gradient is written.
+    // bf16 only, and only where no dropout sits between the layers (the coefficients must exist before the launch:
+    // they do when the BN-backward sums come from the weight gradient).  CPNATIVE_UNFUSED_BN_BWD (read per call)
+    // keeps the separate pass, for the test that compares the two orders.
+    bool bn_done = false;
+    const bool fuse_ok = sizeof(T) == 2 && !getenv("CPNATIVE_UNFUSED_BN_BWD");
     for (int L = 8; L >= 2; --L) {
         const int i = L - 2, Lp = L - 1, K = fcK(i);
-        {
+        if (!bn_done) {
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;
             const float* pp = pre(nr, 2 * 512);
@@ -857,7 +864,34 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         a.W = base + w.wfc_t[i]; a.F = K;
         a.C = nxt; a.ldc = K; a.R = in_drop ? act(Lp) : nullptr; a.ldr = K; a.partials = partials;
         if (in_drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
-        {
+        bn_done = false;
+        if (fuse_ok && !in_drop) {
+            // layer Lp's BN-backward sums exist already (from the weight gradient above): finalise its coefficients
+            // now and let this launch's epilogue apply BN backward + the ReLU mask to its own output tile
+            const int Cp = kLayerC[Lp], nfold = K / Cp;                   // fc below: 512 x 1; conv2 below: 64 x 12
+            {
+                ProfScope ps(CP_K_BN_BWD, st);
+                int nr = stat_rows;
+                const float* pp = pre(nr, 2 * K);
+                hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / 64), dim3(256), 0, st, pp, nr, (double)N * nfold, stats(Lp), coef,
+                                   g->bn_g[Lp], g->bn_b[Lp], Cp, nfold);
+                CKL("bn_bwd_finalize_kernel(fused)");
+            }
+            a.R = act(Lp); a.coef = coef; a.coef_mod = Cp;
+            {
+                ProfScope ps(CP_K_FC_DGRAD_STATS, st);                     // the one-tile-per-block kernel with its R epilogue
+                CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
+            }
+            {
+                ProfScope ps(CP_K_BN_BWD, st);
+                int nr = tiles_n * nfold;                                 // rows of K = nfold rows of Cp
+                const float* pp = pre(nr, Cp);
+                float* db = Lp >= 2 ? g->fc_b[i - 1] : g->conv2_b;
+                hipLaunchKernelGGL(colsum_finalize_kernel, dim3(Cp >= 512 ? 2 : 1), dim3(Cp >= 512 ? 256 : 64), 0, st, pp, nr, Cp, db);
+                CKL("colsum_finalize_kernel(fused)");
+            }
+            bn_done = true;
+        } else {
             // two kinds = two kernels: with input dropout the launch also reduces the BN-backward sums against
             // the saved activation (one-tile-per-block kernel), otherwise it is the persistent kernel
             ProfScope ps(in_drop ? CP_K_FC_DGRAD_STATS : CP_K_FC_DGRAD, st);
@@ -867,7 +901,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     }
     // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
     {
-        {
+        if (!bn_done) {
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
             const float* pp = pre(nr, 2 * 768);

@@ -23,6 +23,8 @@ struct GemmNTArgs {
     const float* bias;   // [F] (EPI_FWD) or nullptr
     const void* R;       // [M][ldr] T  saved post-ReLU activation (EPI_DGRAD)
     float* partials;     // [tiles_m][2][F] per-block column sums (EPI_FWD: v, v^2; EPI_DGRAD: g, g*r)
+    const float* coef;   // EPI_DGRAD (256-tile staged kernel) with R: [3][coef_mod] BN-backward coefficients of the layer BELOW;
+    int coef_mod;        //   the epilogue then writes  r > 0 ? ca*g + cb*r + cz : 0  (feature f uses entry f % coef_mod)
     const float* a_scale;  // ALOAD_CONV affine per input channel (64) or nullptr
     const float* a_shift;
     int64_t M;

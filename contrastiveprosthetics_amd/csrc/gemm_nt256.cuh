@@ -275,6 +275,20 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
     // (R == nullptr: the caller derives the BN-backward sums from the weight gradient instead --
     //  bn_bwd_sums_from_wgrad_kernel -- and this launch neither reads R nor reduces anything)
     const bool with_stats = (EPI == EPI_FWD) || (a.R != nullptr);
+    // a.coef: this launch produces the gradient that ENTERS the layer below and the layer's BN-backward coefficients
+    // are already known (its sums were derived from the weight gradient, bn_bwd_sums_from_wgrad_kernel): apply
+    // BatchNorm backward (step 2) and the ReLU mask here, on the tile that is in LDS anyway, against the saved
+    // activation that this epilogue already knows how to fetch -- instead of a separate in-place pass over the
+    // gradient (read 2 x N x F, write N x F).  The column sums of the result are the layer's bias gradient.
+    const bool bnrelu = (EPI == EPI_DGRAD) && a.coef != nullptr && a.R != nullptr;
+    float kca[EPC], kcb[EPC], kcz[EPC];
+    if (bnrelu) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int ch = (f0 + cc * EPC + e) % a.coef_mod;
+            kca[e] = a.coef[ch]; kcb[e] = a.coef[a.coef_mod + ch]; kcz[e] = a.coef[2 * a.coef_mod + ch];
+        }
+    }
     uint4 rpre[BM / RPP];
     if (EPI == EPI_DGRAD && with_stats) {
 #pragma unroll
@@ -300,6 +314,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
                 float rv[EPC];
                 const uint4 rc = with_stats ? rpre[p] : make_uint4(0, 0, 0, 0);
                 D::unpack(rc, rv);
+                if (bnrelu) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = rv[e] > 0.f ? fmaf(kca[e], v[e], fmaf(kcb[e], rv[e], kcz[e])) : 0.f;
+                    c = D::pack(v);
+                }
                 if (a.dp_thresh != 0) {
 #pragma unroll
                     for (int e = 0; e < EPC; e += 2) {
@@ -339,7 +358,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) s += red[(which * 8 + q) * BN + col];
-        a.partials[(tile_m * 2 + which) * a.F + f0 + col] = s;
+        if (bnrelu) {
+            if (which == 0) a.partials[tile_m * a.F + f0 + col] = s;         // bias gradient: rows of F
+        } else {
+            a.partials[(tile_m * 2 + which) * a.F + f0 + col] = s;
+        }
     }
 }
 

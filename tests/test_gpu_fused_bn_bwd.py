@@ -1,0 +1,49 @@
+"""bf16 backward with BatchNorm + ReLU backward applied in the data-gradient epilogue (the default where no dropout sits
+between two layers) against the same step with the separate in-place pass (CPNATIVE_UNFUSED_BN_BWD, read per call by the
+library).  The only arithmetic difference: the separate pass sees the incoming gradient rounded to bf16 first.
+40,000 rows = 157 sample tiles (ragged last tile); dp = 0 fuses all seven fc layers and conv2, dp > 0 only fc1..fc3 and
+conv2 (dropout follows fc4..fc7)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = 41
+
+
+@pytest.mark.parametrize("dp", [0.0, 0.0635])
+def test_bf16_fused_bn_backward_equals_separate_pass(dp, monkeypatch):
+    from contrastiveprosthetics_amd.engine import Engine
+    n = 40000 - 40000 % T
+    g = torch.Generator().manual_seed(3)
+    mu = torch.randn(T, 12, generator=g)
+    x = (mu[None] + torch.randn(n // T, T, 12, generator=g)).reshape(n, 12).cuda()
+    labels = torch.arange(T).repeat(n // T).cuda()
+    grads = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("CPNATIVE_UNFUSED_BN_BWD", "1")
+        else:
+            monkeypatch.delenv("CPNATIVE_UNFUSED_BN_BWD", raising=False)
+        e = Engine(adabn=False, dtype="bf16", dp_emg=dp, device="cuda", seed=123)
+        e.init_parameters(5)
+        gg = torch.Generator().manual_seed(9)
+        for k in e.specs:                                    # non-trivial BN affine
+            if ".bn" in k or k.split(".")[-2] in ("2", "5", "8", "11", "15", "19", "23"):
+                v = e.values.views[k]
+                if v.dim() == 1 and "linear" in k or "conv_emg.2" in k or "conv_emg.5" in k:
+                    v.copy_((1.0 + 0.2 * torch.randn(v.shape, generator=gg) if k.endswith("weight") else 0.1 * torch.randn(v.shape, generator=gg)).cuda())
+        e.grads.flat.zero_()
+        z = e.encoder_forward(x, training=True)
+        e.head(z, labels, 1, want_grad=True)
+        e.encoder_backward(x)
+        torch.cuda.synchronize()
+        assert torch.isfinite(e.grads.flat).all()
+        grads.append({k: e.grads.views[k].clone() for k in e.specs})
+    for k in grads[0]:
+        a, b = grads[0][k].double().flatten(), grads[1][k].double().flatten()
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos = float(a @ b / (a.norm() * b.norm()))
+        rel = float((a - b).norm() / b.norm())
+        assert cos > 0.9995 and rel < 3e-2, (k, cos, rel)
