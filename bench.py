@@ -262,7 +262,7 @@ def main():
                     mfma_tflops=tfl, mfma_frac=tfl / mfma_peak, hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
                     gemm_ms_per_step={k: prof[k][0] / args.steps for k in gemm_kinds if k in prof},
                     per_kernel=per_kernel)
-        rec = dict(metric="sEMG windows/sec contrastive step, 12-ch Ninapro", value=world * N * args.steps / elapsed,
+        rec = dict(metric="sEMG windows/sec contrastive step, 12-ch Ninapro, 1/2/4/8 MI355X", value=world * N * args.steps / elapsed,
                    unit="windows/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=args.dtype, data="synthetic",
