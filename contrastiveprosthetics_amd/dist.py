@@ -32,12 +32,16 @@ def init_from_env(backend: str = None) -> Tuple[int, int]:
     if w <= 1 or td.is_initialized():
         return rank(), world_size()
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # CP_DIST_BACKEND=gloo: rehearsal of the multi-rank training flow on a box with fewer GPUs than ranks
+        # (ranks share devices, collectives go through gloo); production is nccl == RCCL, one GPU per rank
+        backend = os.environ.get("CP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         td.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         td.init_process_group(backend)
     return rank(), world_size()
 
