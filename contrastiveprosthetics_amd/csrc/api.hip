@@ -243,7 +243,7 @@ static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int
     }
 }
 
-// persistent conv strip kernels: blocks per CU allowed by their LDS footprint (bf16 70 KB, f32 116 KB)
+// persistent conv strip kernels: blocks per CU allowed by their registers (bf16: 2) and LDS footprint (f32 100 KB: 1)
 template <typename T>
 static inline int conv_grid(int64_t n_windows) {
     const int64_t strips = (n_windows + CONV_WPB - 1) / CONV_WPB;

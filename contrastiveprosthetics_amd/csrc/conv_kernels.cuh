@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256) void conv1_materialize_kernel(const float* __r
 //   MODE 1: image = g_y2 strip from HBM;        out = g_v1;                sums: g, g * r1(recomputed)
 // 4 waves: wave w computes feature tile (w&1) x sample tiles 3*(w>>1)+{0,1,2} of the 192 x 64 strip.
 // ------------------------------------------------------------------------------------------
+// LDS: image/output region + weights = 54 KB in bf16 (the final block reduction reuses the region).  Two blocks per CU:
+// the kernel needs 198-234 VGPRs; capping it at 168 for a third block (__launch_bounds__(256, 3)) spilled 30-61
+// registers and ran 2x slower (0.39 / 0.32 ms against 0.15 / 0.18 ms for forward / data gradient at 167,936 windows).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
     using D = DT<T>;
@@ -147,11 +150,12 @@ __global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
     constexpr int IMG_BYTES = CONV_IMG_ROWS * ROWB, C_BYTES = CONV_ROWS * CPITCH;
     constexpr int REGION = IMG_BYTES > C_BYTES ? IMG_BYTES : C_BYTES;
     constexpr int W_BYTES = 64 * WPITCH;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[REGION + W_BYTES + 2 * RPP * 64 * 4];
+    static_assert(REGION >= 2 * RPP * 64 * 4, "the end-of-kernel reduction reuses the image region");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[REGION + W_BYTES];
     unsigned char* img = smem;
     unsigned char* Cs = smem;                      // aliases the image once the MFMAs are done
     unsigned char* Wl = smem + REGION;
-    float* red = (float*)(smem + REGION + W_BYTES);
+    float* red = (float*)smem;                     // used after the strip loop only (which ends with a barrier)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
