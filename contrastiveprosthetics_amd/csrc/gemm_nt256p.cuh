@@ -23,6 +23,11 @@
 // 128 accumulator registers live the fetched tile and the coefficients did not fit: 53-63 spilled VGPRs,
 // +160..220 us per launch against the 94 us of the separate pass it replaced (which already streams at
 // 5.5 TB/s).
+//
+// Also measured: staging through registers (global_load_dwordx4 at the start of a K step, ds_write_b128 at its end)
+// to avoid the LDS-DMA issue cost (8 issues per wave per K step, 100-185 cycles each beside ds_reads and MFMAs).  With
+// 128 accumulator + 48 fragment registers live there is no room for the 32 staging registers: hipcc parks them in
+// scratch right after the loads (a vmcnt wait + scratch_store per load), 338 us against 131 us.
 #pragma once
 #include "gemm_nt256.cuh"
 
