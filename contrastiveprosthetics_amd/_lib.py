@@ -34,8 +34,8 @@ class cp_bn_buffers(C.Structure):
 class cp_config(C.Structure):
     _fields_ = [
         ("n_windows", C.c_int64), ("dtype", C.c_int32), ("adabn", C.c_int32),
-        ("training", C.c_int32), ("reserved", C.c_int32),
-        ("dp_emg", C.c_float), ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("reserved2", C.c_float),
+        ("training", C.c_int32), ("step_state_lo", C.c_uint32),
+        ("dp_emg", C.c_float), ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("step_state_hi", C.c_uint32),
         ("seed", C.c_uint64), ("step", C.c_uint64),
     ]
 
@@ -78,6 +78,8 @@ SYMBOLS = {
                               _P(cp_adam_hyper), _fp, _fp, _fp]),
     "cp_l2_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32),
                                   C.c_int32, _P(cp_adam_hyper), C.c_int64, _fp, _fp, _fp]),
+    "cp_l2_adam_step_graph": (C.c_int, [_fp, _fp, _fp, _fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32),
+                                        C.c_int32, _P(cp_adam_hyper), _fp, _fp, _fp, _fp]),
     "cp_profile_enable": (C.c_int, [C.c_uint64, C.c_int32]),
     "cp_profile_disable": (C.c_int, []),
     "cp_profile_summary": (C.c_int, [C.c_int32, _P(C.c_double), _P(C.c_int64)]),

@@ -176,10 +176,16 @@ static uint32_t host_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+// device cp_step_state of a graph-replayed step (cp_config.step_state_lo/hi), or nullptr
+static const uint32_t* dp_salt(const cp_config* c) {
+    const uint64_t addr = ((uint64_t)c->step_state_hi << 32) | (uint64_t)c->step_state_lo;
+    return (const uint32_t*)(uintptr_t)addr;       // first word of the struct = dp_salt
+}
 static uint32_t dp_key(const cp_config* c, int layer) {
+    const uint64_t step = dp_salt(c) ? 0 : c->step;          // graph mode: the step enters through the device salt
     return host_hash32((uint32_t)c->seed ^ host_hash32((uint32_t)(c->seed >> 32) + 0x51ed27U) ^
-                       host_hash32((uint32_t)c->step * 0x9E3779B1U + (uint32_t)layer * 0x85EBCA77U +
-                                   (uint32_t)(c->step >> 32)));
+                       host_hash32((uint32_t)step * 0x9E3779B1U + (uint32_t)layer * 0x85EBCA77U +
+                                   (uint32_t)(step >> 32)));
 }
 static uint32_t dp_thresh(float p) {
     double t = (double)p * 65536.0 + 0.5;
@@ -328,7 +334,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
             T* u = (T*)(base + w.u[Lp - 5]);
             ProfScope ps(CP_K_DROPOUT, st);
             hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N * 512 / D::EPC, 256, 4096)), dim3(256), 0, st,
-                               act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg));
+                               act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c));
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
         }
@@ -359,7 +365,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
             T* u = (T*)(base + w.u[Lp - 5]);
             ProfScope ps(CP_K_DROPOUT, st);
             hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N * 512 / D::EPC, 256, 4096)), dim3(256), 0, st,
-                               act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg));
+                               act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c));
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
         }
@@ -797,7 +803,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         a.A = dz; a.lda = 64; a.M = N; a.K = 64;
         a.W = base + w.wlast_t; a.F = 512;
         a.C = cur; a.ldc = 512; a.R = drop ? act(8) : nullptr; a.ldr = 512; a.partials = partials;
-        if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
+        if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
     }
     // ---- fc7 .. fc1 --------------------------------------------------------------------
@@ -863,7 +869,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         a.A = cur; a.lda = 512; a.M = N; a.K = 512;
         a.W = base + w.wfc_t[i]; a.F = K;
         a.C = nxt; a.ldc = K; a.R = in_drop ? act(Lp) : nullptr; a.ldr = K; a.partials = partials;
-        if (in_drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); }
+        if (in_drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         bn_done = false;
         if (fuse_ok && !in_drop) {
             // layer Lp's BN-backward sums exist already (from the weight gradient above): finalise its coefficients
@@ -1035,6 +1041,26 @@ extern "C" int cp_l2_adam_step(float* params_flat, const float* grads_flat, floa
     a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.grad_scale = h->grad_scale;
     a.bc1 = (float)(1.0 - pow((double)h->beta1, (double)step_index));
     a.bc2 = (float)(1.0 - pow((double)h->beta2, (double)step_index));
+    ProfScope ps(CP_K_OPT, (hipStream_t)stream);
+    if (int e = launch_norms(a, scratch, l2_out, (hipStream_t)stream)) return e;
+    hipLaunchKernelGGL(adam_kernel, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);
+    CKL("adam_kernel");
+    return 0;
+}
+
+extern "C" int cp_l2_adam_step_graph(float* params_flat, const float* grads_flat, float* exp_avg, float* exp_avg_sq,
+                                     const int64_t* offset_host, const int64_t* numel_host, const int32_t* group_host,
+                                     const int32_t* l2_host, int32_t n, const cp_adam_hyper* h, const cp_step_state* state_dev,
+                                     float* scratch, float* l2_out, void* stream) {
+    if (!params_flat || !grads_flat || !exp_avg || !exp_avg_sq || !h || !scratch || !l2_out || !state_dev)
+        return fail(CP_ERR_ARG, "cp_l2_adam_step_graph args");
+    OptArgs a{};
+    if (int e = build_opt(&a, offset_host, numel_host, group_host, l2_host, n)) return e;
+    a.p = params_flat; a.g = grads_flat; a.m = exp_avg; a.v = exp_avg_sq;
+    a.lr[0] = h->lr_emg; a.lr[1] = h->lr_glove; a.reg[0] = h->reg_emg; a.reg[1] = h->reg_glove;
+    a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.grad_scale = h->grad_scale;
+    a.bc1 = a.bc2 = 1.f;
+    a.state = (const float*)state_dev;
     ProfScope ps(CP_K_OPT, (hipStream_t)stream);
     if (int e = launch_norms(a, scratch, l2_out, (hipStream_t)stream)) return e;
     hipLaunchKernelGGL(adam_kernel, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);

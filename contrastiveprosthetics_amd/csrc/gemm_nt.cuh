@@ -35,6 +35,7 @@ struct GemmNTArgs {
     int dbg;             // ablation (tools/gemm_bench.py only): 1 skip MFMA, 2 skip epilogue, 4 skip staging loads
     // dropout on the gradient (EPI_DGRAD); thresh == 0 -> none
     uint32_t dp_thresh, dp_key;
+    const uint32_t* dp_salt;   // optional device word XOR-ed into dp_key (graph replay: the per-step part of the key)
     float dp_inv_keep;
 };
 
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
                     if (a.dp_thresh != 0) {
 #pragma unroll
                         for (int e = 0; e < EPC; e += 2) {
-                            const uint32_t pr = dropout_pair(a.dp_key, (uint32_t)m, (uint32_t)a.ldc, (uint32_t)(f + e));
+                            const uint32_t pr = dropout_pair(a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key, (uint32_t)m, (uint32_t)a.ldc, (uint32_t)(f + e));
                             v[e] *= dropout_scale(pr, 0, a.dp_thresh, a.dp_inv_keep);
                             v[e + 1] *= dropout_scale(pr, 1, a.dp_thresh, a.dp_inv_keep);
                         }

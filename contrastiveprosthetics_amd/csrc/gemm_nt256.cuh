@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
                 if (a.dp_thresh != 0) {
 #pragma unroll
                     for (int e = 0; e < EPC; e += 2) {
-                        const uint32_t pr = dropout_pair(a.dp_key, (uint32_t)m, (uint32_t)a.ldc, (uint32_t)(f + e));
+                        const uint32_t pr = dropout_pair(a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key, (uint32_t)m, (uint32_t)a.ldc, (uint32_t)(f + e));
                         v[e] *= dropout_scale(pr, 0, a.dp_thresh, a.dp_inv_keep);
                         v[e + 1] *= dropout_scale(pr, 1, a.dp_thresh, a.dp_inv_keep);
                     }

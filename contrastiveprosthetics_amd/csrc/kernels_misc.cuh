@@ -147,9 +147,10 @@ __global__ void prep_conv2_kernel(const float* __restrict__ W, T* __restrict__ f
 template <typename T>
 __global__ __launch_bounds__(256) void bn_dropout_apply_kernel(const T* __restrict__ r, const float* __restrict__ stats,
                                                                T* __restrict__ u, int64_t rows, int C, uint32_t thresh,
-                                                               uint32_t key, float inv_keep) {
+                                                               uint32_t key, float inv_keep, const uint32_t* __restrict__ salt) {
     using D = DT<T>;
     constexpr int EPC = D::EPC;
+    if (salt) key ^= *salt;                        // graph replay: the per-step part of the key lives in device memory
     const int cpr = C / EPC;
     const int64_t total = rows * cpr;
     const float* s = stats + 2 * C;

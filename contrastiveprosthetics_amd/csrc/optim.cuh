@@ -28,6 +28,7 @@ struct OptArgs {
     int n_tensors, total_chunks;
     float lr[2], reg[2];
     float beta1, beta2, eps, bc1, bc2, grad_scale;
+    const float* state;     // optional device cp_step_state: [1] bc1, [2] bc2, [3] lr_emg, [4] lr_glove override the values above
     OptTensor t[CP_MAX_TENSORS];
 };
 
@@ -81,10 +82,10 @@ __global__ __launch_bounds__(256) void adam_kernel(OptArgs a) {
     const int ti = opt_find_tensor(a, chunk);
     const OptTensor& t = a.t[ti];
     const int64_t base = (int64_t)(chunk - t.chunk0) * OPT_CHUNK;
-    const float lr = a.lr[t.group];
+    const float lr = a.state ? a.state[3 + t.group] : a.lr[t.group];
     const float l2c = t.l2 ? a.reg[t.group] / a.norms[ti] : 0.f;
-    const float step = lr / a.bc1;
-    const float rs2 = 1.0f / sqrtf(a.bc2);
+    const float step = lr / (a.state ? a.state[1] : a.bc1);
+    const float rs2 = 1.0f / sqrtf(a.state ? a.state[2] : a.bc2);
     for (int i = threadIdx.x; i < OPT_CHUNK; i += 256) {
         const int64_t e = base + i;
         if (e >= t.numel) break;

@@ -212,6 +212,7 @@ class Engine:
                 self._gp.running_var = self.running[gb + ".running_var"].data_ptr()
         self._gws: Optional[torch.Tensor] = None
         self._gws_rows = 0
+        self._graph_state: Optional[torch.Tensor] = None      # device cp_step_state while a GraphStep owns the engine
         self._ws: Optional[torch.Tensor] = None
         self._ws_windows = 0
         names = list(self.specs)
@@ -230,6 +231,9 @@ class Engine:
 
     def _cfg(self, n_windows: int, training: bool) -> _lib.cp_config:
         c = _lib.cp_config()
+        if self._graph_state is not None:          # capturing / replaying a step graph: per-step values come from device memory
+            addr = self._graph_state.data_ptr()
+            c.step_state_lo, c.step_state_hi = addr & 0xFFFFFFFF, addr >> 32
         c.n_windows = n_windows
         c.dtype = self.dtype
         c.adabn = 1 if self.adabn else 0
@@ -391,6 +395,16 @@ class Engine:
                                             self._stream()), "cp_l2_adam_step")
         return self._l2_out
 
+    def adam_step_graph(self, params: dict, grad_scale: float = 1.0) -> torch.Tensor:
+        """cp_l2_adam_step with learning rates and bias corrections read from the device step state (graph capture)."""
+        h = self._hyper(params, grad_scale)
+        _lib.check(self.lib.cp_l2_adam_step_graph(self.values.flat.data_ptr(), self.grads.flat.data_ptr(),
+                                                  self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self._tab_off,
+                                                  self._tab_numel, self._tab_group, self._tab_l2, self._tab_n, C.byref(h),
+                                                  self._graph_state.data_ptr(), self._opt_scratch.data_ptr(),
+                                                  self._l2_out.data_ptr(), self._stream()), "cp_l2_adam_step_graph")
+        return self._l2_out
+
     # ------------------------------------------------------------------ debug (tests)
     def debug_activation(self, layer: int) -> torch.Tensor:
         n, training = self._last
@@ -462,3 +476,96 @@ class Engine:
                 self.running[k].copy_(sd[k].to(self.device))
                 if k.endswith("num_batches_tracked"):
                     self.num_batches_tracked = int(sd[k])
+
+
+class GraphStep:
+    """One whole training step -- gather, encoder forward, head, backward, L2 + Adam, ~110 kernel launches -- captured
+    once in a HIP graph and replayed with a single launch.  At the reference's batch sizes (8..32 groups) a step is
+    launch-latency-bound, so this is where its wall time goes.  What changes from step to step is not baked into
+    the graph: the batch indices live in a fixed device buffer, and the dropout salt, Adam's bias corrections and
+    the (scheduled) learning rates in a 32-byte device `cp_step_state` refreshed by one async copy per step.
+    One instance per (engine, batch size); the class encoder is the one-hot table or, with `glove_table`, the glove one."""
+
+    def __init__(self, engine: "Engine", table: torch.Tensor, emg_rand: torch.Tensor, batch: int, params: dict,
+                 grad_scale: float = 1.0, glove=None):
+        self.e = engine
+        self.params = dict(params)
+        self.B = int(batch)
+        dev = engine.device
+        self.perm = torch.zeros(self.B, dtype=torch.int64, device=dev)
+        self.labels = torch.arange(CP_TASKS, device=dev).repeat(self.B)
+        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        self.glove = glove                                  # callable perm -> (B,41,20) tensor, or None
+        self.lr_scale = [1.0, 1.0]
+        # the sampler table is re-drawn by TaskWrapper.reset() every epoch: the graph reads a copy at a fixed address
+        self.table, self.emg_rand = table, emg_rand.clone()
+        engine.workspace(self.B * CP_TASKS)
+        self._push()
+        # the warm-up below is a real step on real state, and capturing runs the host side of every call once more:
+        # snapshot what they touch and put it back
+        keep = (engine.values.flat.clone(), engine.exp_avg.clone(), engine.exp_avg_sq.clone(),
+                {k: v.clone() for k, v in engine.running.items()}, engine.step_count, engine.adam_steps,
+                engine.num_batches_tracked)
+        engine._graph_state = self.state
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                   # warm-up outside the capture (lazy module loads, allocator)
+                self._body(grad_scale)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            # the warm-up was a real step on real state: roll the optimiser state back
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._body(grad_scale)
+        finally:
+            engine._graph_state = None
+            engine.values.flat.copy_(keep[0]); engine.exp_avg.copy_(keep[1]); engine.exp_avg_sq.copy_(keep[2])
+            for k, v in keep[3].items():
+                engine.running[k].copy_(v)
+            engine.step_count, engine.adam_steps, engine.num_batches_tracked = keep[4], keep[5], keep[6]
+
+    def _body(self, grad_scale):
+        e = self.e
+        x = e.gather(self.table, self.emg_rand, self.perm, 1)
+        z = e.encoder_forward(x, training=True)
+        if self.glove is not None:
+            zg = e.glove_forward(self.glove(self.perm), training=True)
+            out, pred, _ = e.head_glove(z, zg, self.labels, 1, want_grad=True)
+            e.encoder_backward(x)
+            e.glove_backward()
+        else:
+            out, pred, _ = e.head(z, self.labels, 1, want_grad=True)
+            e.encoder_backward(x)
+        e.adam_step_graph(self.params, grad_scale)
+        return out
+
+    def _push(self):
+        e = self.e
+        t = e.adam_steps + 1
+        h = self._host
+        salt = (e.step_count + 1) * 0x9E3779B1 & 0xFFFFFFFF
+        h.view(torch.int32)[0] = salt - (1 << 32) if salt >= (1 << 31) else salt
+        b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))   # the betas as the C side holds them (float)
+        h[1] = 1.0 - b1 ** t
+        h[2] = 1.0 - b2 ** t
+        h[3] = float(self.params.get("lr_emg", 0.0)) * self.lr_scale[0]
+        h[4] = float(self.params.get("lr_glove", 0.0)) * self.lr_scale[1]
+        self.state.copy_(h, non_blocking=True)
+
+    def set_sampler(self, emg_rand: torch.Tensor):
+        """TaskWrapper.reset() drew a new (41, D) table: refresh the graph's copy (same shape)."""
+        self.emg_rand.copy_(emg_rand)
+
+    def step(self, perm: torch.Tensor) -> torch.Tensor:
+        """perm: the B item indices of this batch (device int64).  Returns the device tensor (loss, #correct)."""
+        self.perm.copy_(perm, non_blocking=True)
+        self._push()
+        self.graph.replay()
+        e = self.e
+        e.step_count += 1
+        e.adam_steps += 1
+        if not e.adabn:
+            e.num_batches_tracked += 1
+        return self.out

@@ -19,6 +19,7 @@ import torch
 
 from . import dist as cpdist
 from .load import DB23
+from .engine import GraphStep
 from .models import Model
 from .utils import GroupLoader, TaskWrapper
 
@@ -75,6 +76,8 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
     loader = GroupLoader(dataset, args.batch_size, shuffle=shuff, rank=rank, world=world, generator=gen)
     val_losses = {}
     final_val_acc = None
+    use_graph = bool(getattr(args, "graph", False)) and world == 1 and model.class_encoder == "onehot"
+    graph_step = None
     print("Training...")
     for e in range(epochs):
         # schedulers of code/train.py:75-80,112-113 as closed forms applied to the fused optimiser's lr
@@ -86,7 +89,24 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
         loss_train = []
         t0 = time.time()
         nwin = 0
-        for (EMG, GLOVE, label) in loader:
+        if use_graph:
+            # the whole step as ONE graph launch (engine.GraphStep): at these batch sizes a step is ~110 launches of a few
+            # microseconds each.  The loader's order is kept; a short last batch goes through the call-by-call path.
+            if graph_step is None:
+                graph_step = GraphStep(model.engine, dataset.EMG_use, dataset.emg_rand, args.batch_size, model.params)
+            graph_step.set_sampler(dataset.emg_rand)
+            graph_step.lr_scale = list(model.lr_scale)
+            order = torch.randperm(len(dataset), generator=gen).to(model.device)
+            full = (len(dataset) // args.batch_size) * args.batch_size
+            for i in range(0, full, args.batch_size):
+                out = graph_step.step(order[i:i + args.batch_size]).clone()
+                loss_train.append(out[0:1])
+                model.corrects.append(out[1] / float(args.batch_size * 41))
+                nwin += args.batch_size * 41
+            tail = [dataset.batch(order[full:])] if full < len(dataset) else []
+        else:
+            tail = loader
+        for (EMG, GLOVE, label) in tail:
             label = label.reshape(-1)
             logits = model.forward(EMG, GLOVE, label)
             loss = model.loss(logits, label)
@@ -229,6 +249,8 @@ def build_parser():
     parser.add_argument("--checkpoint_dir", default="../checkpoints")
     parser.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],
                         help="glove: class embeddings from the glove-angle rows (zero-shot path, BASELINE config 3)")
+    parser.add_argument("--graph", action="store_true",
+                        help="replay each training step as one captured HIP graph (single process, one-hot class encoder)")
     parser.add_argument("--hpo_pack", action="store_true",
                         help="packed random search: every rank trains its share of the --crossval_size configurations alone "
                              "(any number of ranks per GPU, results gathered over gloo); rank 0 then trains the final model")

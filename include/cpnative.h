@@ -67,14 +67,26 @@ typedef struct cp_config {
     int32_t dtype;       /* CP_F32 | CP_BF16 */
     int32_t adabn;       /* 1: batch statistics in train AND eval (AdaBN); 0: stock BN */
     int32_t training;    /* 1: model.train()  (batch stats, dropout, running-stat update) */
-    int32_t reserved;
+    uint32_t step_state_lo; /* low / high half of the DEVICE address of a cp_step_state, or 0/0 (see below) */
     float dp_emg;        /* Dropout p after BN of fc4..fc7 (code/models.py:282-297) */
     float bn_momentum;   /* 0.1 */
     float bn_eps;        /* 1e-5 */
-    float reserved2;
+    uint32_t step_state_hi;
     uint64_t seed;       /* dropout stream = f(seed, step, layer, element) */
     uint64_t step;
 } cp_config;
+
+/* Per-step values kept in DEVICE memory so that a whole training step can be captured in a HIP graph and replayed
+ * (graphs bake kernel arguments; these are the arguments that change from step to step).  The host refreshes the
+ * 32 bytes with one asynchronous copy before each replay.  When cp_config.step_state_{lo,hi} hold its address, the
+ * dropout stream is f(seed, layer, element) ^ dp_salt (cfg->step is then taken as 0), and cp_l2_adam_step_graph
+ * reads the bias corrections and learning rates from it. */
+typedef struct cp_step_state {
+    uint32_t dp_salt;     /* any function of the step index, e.g. a hash of it */
+    float bc1, bc2;       /* 1 - beta1^t, 1 - beta2^t */
+    float lr_emg, lr_glove;
+    float pad[3];
+} cp_step_state;
 
 int cp_version(void);
 const char* cp_last_error(void);
@@ -199,6 +211,12 @@ typedef struct cp_adam_hyper {
     float lr_emg, lr_glove, reg_emg, reg_glove;
     float beta1, beta2, eps, grad_scale;
 } cp_adam_hyper;
+/* cp_l2_adam_step with lr_emg, lr_glove and the bias corrections read from a device cp_step_state (graph replay);
+ * the other fields of h are used as given. */
+int cp_l2_adam_step_graph(float* params_flat, const float* grads_flat, float* exp_avg, float* exp_avg_sq,
+                          const int64_t* offset_host, const int64_t* numel_host, const int32_t* group_host,
+                          const int32_t* l2_host, int32_t n, const cp_adam_hyper* h, const cp_step_state* state_dev,
+                          float* scratch, float* l2_out, void* stream);
 size_t cp_optimizer_scratch_floats(const int64_t* numel_host, int32_t n);
 int cp_l2_norms(const float* params_flat, const int64_t* offset_host, const int64_t* numel_host,
                 const int32_t* group_host, const int32_t* l2_host, int32_t n, const cp_adam_hyper* h,
