@@ -128,6 +128,25 @@ __global__ void transpose_w_kernel(const float* __restrict__ W, T* __restrict__ 
     }
 }
 
+// the same for several weight matrices in ONE launch (blockIdx.y = job): the 7 fc layers + the projection at the start
+// of the backward pass (8 launches of ~5 us each otherwise)
+struct TransposeJob { const float* W; void* out; int F, K, ld_out, mode; };
+struct TransposeBatch { TransposeJob job[8]; };
+template <typename T>
+__global__ void transpose_w_batch_kernel(TransposeBatch b) {
+    using D = DT<T>;
+    const TransposeJob j = b.job[blockIdx.y];
+    const int64_t total = (int64_t)j.K * j.ld_out;
+    T* out = (T*)j.out;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % j.ld_out);
+        const int kp = (int)(i / j.ld_out);
+        int k = kp;
+        if (j.mode == 1) k = (kp & 63) * 12 + (kp >> 6);
+        D::store(out + i, col < j.F ? j.W[(int64_t)col * j.K + k] : 0.f);
+    }
+}
+
 // conv2 weights (64,64,3,3): kernel row 1 only.
 //   fwd[o][tap*64 + i]  = W[o][i][1][tap]
 //   dgr[i][tap*64 + o]  = W[o][i][1][2 - tap]     (flipped taps for the data gradient)
