@@ -262,8 +262,10 @@ struct PreReduce {
     const float* partials;
     float* scratch;
     hipStream_t st;
-    const float* operator()(int& nrows, int W) const {
-        if (nrows <= 2 * REDUCE_SLICES) return partials;      // (128 rows finalized directly measured slower than reduce + finalize)
+    // direct_rows: how many rows the consumer walks without help (the 16-lane finalize kernels: FIN_DIRECT_ROWS; kernels
+    // that walk rows with one thread per column: 2 * REDUCE_SLICES)
+    const float* operator()(int& nrows, int W, int direct_rows = FIN_DIRECT_ROWS) const {
+        if (nrows <= direct_rows) return partials;
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(W / 64, REDUCE_SLICES), dim3(256), 0, st, partials, nrows, W, scratch);
         nrows = REDUCE_SLICES;
         return scratch;
@@ -288,7 +290,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const int C = kLayerC[l];
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
         const float* pp = batch_stats ? pre(nrows, 2 * C) : partials;
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(256), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(FIN_THREADS), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
                            have_running ? bn->running_mean[l] : nullptr, have_running ? bn->running_var[l] : nullptr, upd,
                            batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats(l), C);
         hipError_t e = hipGetLastError();
@@ -425,7 +427,7 @@ extern "C" int cp_head(const cp_config* cfg, const cp_params* p, const float* z,
     CKL("head_kernel");
     int nr = blocks;
     const PreReduce pre{a.partials, (float*)(base + w.partials2), st};
-    const float* pp = pre(nr, HEAD_PART);
+    const float* pp = pre(nr, HEAD_PART, 2 * REDUCE_SLICES);
     hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, n_groups, p->easy_w, p->easy_b,
                        want_grad, loss_correct, want_grad ? grads->easy_w : nullptr, want_grad ? grads->easy_b : nullptr);
     CKL("head_finalize_kernel");
@@ -599,7 +601,7 @@ static int glove_forward_t(const cp_config* c, const cp_glove_params* gp, const 
         int nrows = (int)((R + 127) / 128);
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
         const float* pp = batch_stats ? pre(nrows, 2 * GL_H) : partials;
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(GL_H / 64), dim3(256), 0, st, pp, nrows, (double)R, gp->bn_g, gp->bn_b,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(GL_H / 64), dim3(FIN_THREADS), 0, st, pp, nrows, (double)R, gp->bn_g, gp->bn_b,
                            have_running ? gp->running_mean : nullptr, have_running ? gp->running_var : nullptr, upd,
                            batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats, GL_H);
         CKL("bn_finalize_kernel(glove)");
@@ -656,7 +658,7 @@ extern "C" int cp_head_glove(const cp_config* cfg, const float* z, const float* 
     CKL("head_kernel<glove>");
     int nr = blocks;
     const PreReduce pre{a.partials, (float*)(base + w.partials2), st};
-    const float* pp = pre(nr, HEAD_PART);
+    const float* pp = pre(nr, HEAD_PART, 2 * REDUCE_SLICES);
     hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, n_groups, (const float*)nullptr, (const float*)nullptr,
                        0, loss_correct, (float*)nullptr, (float*)nullptr);
     CKL("head_finalize_kernel");
@@ -704,7 +706,7 @@ static int glove_backward_t(const cp_config* c, const cp_glove_params* gp, int64
         CKL("relu_bwd_colsum_kernel");
         int nr = gb;
         const float* pp = pre(nr, 2 * GL_H);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(GL_H / 64), dim3(256), 0, st, pp, nr, (double)R, stats, coef, g->bn_g, g->bn_b, GL_H, 1);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(GL_H / 64), dim3(FIN_THREADS), 0, st, pp, nr, (double)R, stats, coef, g->bn_g, g->bn_b, GL_H, 1);
         CKL("bn_bwd_finalize_kernel(glove)");
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_rows(R * GL_H / D::EPC, 256, 4096)), dim3(256), 0, st, gbuf, h, coef, R, GL_H);
         CKL("bn_bwd_apply_kernel");
@@ -778,7 +780,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             s = stats(8) + 2 * 512; t = stats(8) + 3 * 512;
             const int gb = grid_rows(N, 256 / (CP_D_E / D::EPC), 64);
             hipLaunchKernelGGL((colsum_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, dz, partials, N, 64, CP_D_E);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, partials, gb, CP_D_E, dzsum);  // 16 columns: tiny
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, st, partials, gb, CP_D_E, dzsum);  // 16 columns: tiny
             CKL("colsum(dz)");
         }
         GemmTNArgs ta{};
@@ -818,14 +820,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;
             const float* pp = pre(nr, 2 * 512);
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(256), 0, st, pp, nr, (double)N, stats(L), coef,
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(FIN_THREADS), 0, st, pp, nr, (double)N, stats(L), coef,
                                g->bn_g[L], g->bn_b[L], 512, 1);
             CKL("bn_bwd_finalize_kernel");
             const int gb = grid_rows(N, 256 / (512 / D::EPC), 2048);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
             nr = gb;
             pp = pre(nr, 512);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(2), dim3(256), 0, st, pp, nr, 512, g->fc_b[i]);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(512 / 64), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[i]);
             CKL("bn_relu_bwd_kernel");
         }
         const bool in_drop = drop && Lp >= 5;
@@ -877,7 +879,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 ProfScope ps(CP_K_BN_BWD, st);
                 int nr = stat_rows;
                 const float* pp = pre(nr, 2 * K);
-                hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / 64), dim3(256), 0, st, pp, nr, (double)N * nfold, stats(Lp), coef,
+                hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / 64), dim3(FIN_THREADS), 0, st, pp, nr, (double)N * nfold, stats(Lp), coef,
                                    g->bn_g[Lp], g->bn_b[Lp], Cp, nfold);
                 CKL("bn_bwd_finalize_kernel(fused)");
             }
@@ -891,7 +893,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 int nr = tiles_n * nfold;                                 // rows of K = nfold rows of Cp
                 const float* pp = pre(nr, Cp);
                 float* db = Lp >= 2 ? g->fc_b[i - 1] : g->conv2_b;
-                hipLaunchKernelGGL(colsum_finalize_kernel, dim3(Cp >= 512 ? 2 : 1), dim3(Cp >= 512 ? 256 : 64), 0, st, pp, nr, Cp, db);
+                hipLaunchKernelGGL(colsum_finalize_kernel, dim3(Cp / 64), dim3(FIN_THREADS), 0, st, pp, nr, Cp, db);
                 CKL("colsum_finalize_kernel(fused)");
             }
             bn_done = true;
@@ -909,14 +911,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
             const float* pp = pre(nr, 2 * 768);
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, (double)R12, stats(1), coef,
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(1), coef,
                                g->bn_g[1], g->bn_b[1], 64, 12);
             CKL("bn_bwd_finalize_kernel(conv2)");
             const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
             nr = gb;
             pp = pre(nr, 64);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, st, pp, nr, 64, g->conv2_b);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
             CKL("bn_relu_bwd_kernel(conv2)");
         }
         ConvArgs ca{};
@@ -955,14 +957,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         ProfScope ps(CP_K_CONV1_BWD, st);
         int nr = conv_dgrad_rows;
         const float* pp = pre(nr, 2 * 64);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, (double)R12, stats(0), coef, g->bn_g[0],
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(0), coef, g->bn_g[0],
                            g->bn_b[0], 64, 1);
         CKL("bn_bwd_finalize_kernel(conv1)");
         constexpr int RPP = 256 / (64 / D::EPC);
         const int gb = grid_rows(R12, RPP, 2048);
         hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, x, p->conv1_w, p->conv1_b, coef, partials, R12);
         nr = gb;
-        pp = pre(nr, 4 * 64);
+        pp = pre(nr, 4 * 64, 2 * REDUCE_SLICES);
         hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, g->conv1_w, g->conv1_b);
         CKL("conv1_bwd_kernel");
     }

@@ -37,17 +37,22 @@ __global__ void gather_groups_kernel(const float* __restrict__ table, const int6
 // partials: [nrows][2][C] (sum, sum of squares).  use_running: eval with stock BN.
 // stats out: [4][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nrows, double count,
+// (finalize kernels: 64 columns x blockDim.x/64 row lanes per block, launched with FIN_THREADS = 1024 so that up to
+//  FIN_DIRECT_ROWS partial rows are folded here directly -- 48 rows per lane -- without a reduce_rows_kernel launch first)
+#define FIN_THREADS 1024
+#define FIN_LANES (FIN_THREADS / 64)
+#define FIN_DIRECT_ROWS 768
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* __restrict__ partials, int nrows, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, int update_running,
                                                           int use_running, float momentum, float eps,
                                                           float* __restrict__ stats, int C) {
-    __shared__ double red[2][4][64];
-    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+    __shared__ double red[2][FIN_LANES][64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6, L = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s1 = 0, s2 = 0;
     if (!use_running)
-        for (int r = g; r < nrows; r += 4) {
+        for (int r = g; r < nrows; r += L) {
             s1 += (double)partials[((int64_t)r * 2 + 0) * C + c];
             s2 += (double)partials[((int64_t)r * 2 + 1) * C + c];
         }
@@ -60,8 +65,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
             mean = running_mean[c];
             var = running_var[c];
         } else {
-            s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-            s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+            s1 = s2 = 0;
+            for (int q = 0; q < L; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
             const double mu = s1 / count;
             double vb = s2 / count - mu * mu;
             if (vb < 0) vb = 0;
@@ -195,18 +200,18 @@ __global__ __launch_bounds__(256) void bn_dropout_apply_kernel(const T* __restri
 //   x_hat = (r - mean)*invstd;  dgamma = sum g*x_hat;  dbeta = sum g
 //   g_r = s * (g - mean(g) - x_hat * mean(g*x_hat))
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nrows, double count,
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nrows, double count,
                                                               const float* __restrict__ stats, float* __restrict__ coef,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
                                                               int nfold) {
     // nfold > 1: the partial rows are nfold*C wide (feature = w*C + channel, conv stack seen
     // through the first Linear); the BatchNorm2d channel statistic sums over w.
-    __shared__ double red[2][4][64];
-    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+    __shared__ double red[2][FIN_LANES][64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6, L = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const int W = C * nfold;
     double s1 = 0, s2 = 0;
-    for (int r = g; r < nrows; r += 4)
+    for (int r = g; r < nrows; r += L)
         for (int f = 0; f < nfold; ++f) {
             s1 += (double)partials[((int64_t)r * 2 + 0) * W + f * C + c];
             s2 += (double)partials[((int64_t)r * 2 + 1) * W + f * C + c];
@@ -215,8 +220,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     red[1][g][cl] = s2;
     __syncthreads();
     if (g == 0) {
-        s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        s1 = s2 = 0;
+        for (int q = 0; q < L; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
         const double mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c];
         const double dot = (s2 - mean * s1) * invstd;          // sum g * x_hat
         const double c1 = s1 / count, c2 = dot / count;
@@ -314,12 +319,22 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 }
 
 // out[c] = sum_rows partials[row][c]  (f64 accumulation; one thread per column)
-__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nrows, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// grid ceil(C/64) blocks of FIN_THREADS (64 columns x row lanes)
+__global__ __launch_bounds__(FIN_THREADS) void colsum_finalize_kernel(const float* __restrict__ partials, int nrows, int C,
+                                                                      float* __restrict__ out) {
+    __shared__ double red[FIN_LANES][64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6, L = blockDim.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s = 0;
-    for (int r = 0; r < nrows; ++r) s += (double)partials[(int64_t)r * C + c];
-    out[c] = (float)s;
+    if (c < C)
+        for (int r = g; r < nrows; r += L) s += (double)partials[(int64_t)r * C + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        s = 0;
+        for (int q = 0; q < L; ++q) s += red[q][cl];
+        out[c] = (float)s;
+    }
 }
 
 // dW1[c][0][1][tap] and db1[c] from the partials; the other kernel rows get zero data gradient.
