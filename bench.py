@@ -37,8 +37,9 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 # profiler kind -> (the ONE kernel it times, as rocprofv3 names it; fc layer indices it runs on when dropout is on / off)
 GEMM_KERNELS = {
     "fc_fwd": "gemm_nt256p_kernel<0, 4>",          # persistent, bias + ReLU + BN sums in the epilogue
-    "fc_dgrad": "gemm_nt256p_kernel<1, 4>",        # persistent, plain data gradient (unfused mode only)
-    "fc_dgrad_stats": "gemm_nt256_kernel<1>",      # data gradient whose epilogue works against the saved activation
+    "fc_dgrad": "gemm_nt256p_kernel<1, 4>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
+    "fc_dgrad_bn": "gemm_nt256p_kernel<3, 4>",     # persistent, + BN/ReLU backward of the layer below against the saved activation
+    "fc_dgrad_stats": "gemm_nt256p_kernel<4, 4>",  # persistent, behind a dropout: mask + BN-backward sums against the saved activation
     "fc_wgrad": "gemm_tn256_kernel",
 }
 
@@ -55,10 +56,11 @@ def gemm_model(kind: str, n: int, es: int, dropout: bool):
     elif kind == "fc_dgrad":        # read g_y, write g_v (only with CPNATIVE_UNFUSED_BN_BWD: the plain persistent launch)
         unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD"))
         layers, per = ((range(4) if dropout else range(7)) if unfused else range(0)), lambda k: 512 + k
-    elif kind == "fc_dgrad_stats":  # read g_y and the saved activation, write g_v: behind a dropout the epilogue reduces
-        #                             the BN-backward sums against it, elsewhere it applies BN + ReLU backward with it
+    elif kind == "fc_dgrad_bn":     # read g_y and the saved activation of the layer below, write its dL/d(pre-activation)
         unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD"))
-        layers, per = ((range(4, 7) if dropout else range(0)) if unfused else range(7)), lambda k: 512 + 2 * k
+        layers, per = (range(0) if unfused else (range(4) if dropout else range(7))), lambda k: 512 + 2 * k
+    elif kind == "fc_dgrad_stats":  # behind a dropout: read g_y and the saved activation, write g_v
+        layers, per = (range(4, 7) if dropout else range(0)), lambda k: 512 + 2 * k
     else:                           # fc_wgrad: read g_y and the layer input
         layers, per = range(7), lambda k: 512 + k
     layers = list(layers)
@@ -201,7 +203,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    gemm_kinds = ["fc_fwd", "fc_dgrad", "fc_dgrad_stats", "fc_wgrad"]
+    gemm_kinds = ["fc_fwd", "fc_dgrad", "fc_dgrad_bn", "fc_dgrad_stats", "fc_wgrad"]
     eng.profile_enable(gemm_kinds, max_records=64 * (args.steps + 1))
     barrier()
     t0 = time.perf_counter()

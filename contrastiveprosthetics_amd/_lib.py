@@ -91,7 +91,7 @@ SYMBOLS = {
 
 KERNEL_KINDS = ["gather", "prep", "conv1_fwd", "bn_finalize", "conv2_fwd", "fold", "fc_fwd", "dropout", "proj_fwd",
                 "head", "proj_bwd", "bn_bwd", "fc_wgrad", "reduce_slabs", "fc_dgrad", "conv2_wgrad", "conv2_dgrad",
-                "conv1_bwd", "optimizer", "fc_dgrad_stats"]
+                "conv1_bwd", "optimizer", "fc_dgrad_stats", "fc_dgrad_bn"]
 
 _lib = None
 

@@ -243,6 +243,10 @@ static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int
     if (stat_rows) *stat_rows = (int)((a.M + fc_bm<T>() - 1) / fc_bm<T>());
     if constexpr (sizeof(T) == 2) {
         if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows);
+        if (EPI == EPI_DGRAD && a.R != nullptr && !(a.dbg & 16) && !getenv("CPNATIVE_STAGED_R_EPILOGUE")) {
+            // the persistent kernel's R epilogues: BN + ReLU backward of the layer below (coef), or dropout + BN-backward sums
+            return a.coef ? launch_gemm_nt256p<EPI_DGRAD_BN>(a, st, stat_rows) : launch_gemm_nt256p<EPI_DGRAD_ST>(a, st, stat_rows);
+        }
         return launch_gemm_nt256<EPI>(a, st);
     } else {
         return launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI>(a, st);
@@ -804,7 +808,9 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         a.W = base + w.wlast_t; a.F = 512;
         a.C = cur; a.ldc = 512; a.R = drop ? act(8) : nullptr; a.ldr = 512; a.partials = partials;
         if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
-        CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
+        int drows = 0;
+        CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
+        if (drop) stat_rows = drows;                 // partial rows of BN-backward sums written by this launch
     }
     // ---- fc7 .. fc1 --------------------------------------------------------------------
     // bn_done: BatchNorm + ReLU backward of layer L were applied by the data-gradient launch of the layer above (its
@@ -884,13 +890,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 CKL("bn_bwd_finalize_kernel(fused)");
             }
             a.R = act(Lp); a.coef = coef; a.coef_mod = Cp;
+            int drows = 0;
             {
-                ProfScope ps(CP_K_FC_DGRAD_STATS, st);                     // the one-tile-per-block kernel with its R epilogue
-                CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
+                ProfScope ps(CP_K_FC_DGRAD_BN, st);                        // data gradient + BN/ReLU backward of the layer below
+                CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
             }
             {
                 ProfScope ps(CP_K_BN_BWD, st);
-                int nr = tiles_n * nfold;                                 // rows of K = nfold rows of Cp
+                int nr = drows * nfold;                                   // rows of K = nfold rows of Cp
                 const float* pp = pre(nr, Cp);
                 float* db = Lp >= 2 ? g->fc_b[i - 1] : g->conv2_b;
                 hipLaunchKernelGGL(colsum_finalize_kernel, dim3(Cp / 64), dim3(FIN_THREADS), 0, st, pp, nr, Cp, db);
@@ -901,7 +908,9 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // two kinds = two kernels: with input dropout the launch also reduces the BN-backward sums against
             // the saved activation (one-tile-per-block kernel), otherwise it is the persistent kernel
             ProfScope ps(in_drop ? CP_K_FC_DGRAD_STATS : CP_K_FC_DGRAD, st);
-            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
+            int drows = 0;
+            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
+            if (in_drop) stat_rows = drows;
         }
         T* tmp = cur; cur = nxt; nxt = tmp;
     }

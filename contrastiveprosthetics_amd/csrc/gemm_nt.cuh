@@ -14,7 +14,9 @@
 #include "common.cuh"
 
 enum { ALOAD_PLAIN = 0, ALOAD_CONV = 1 };
-enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_PLAIN_F32 = 2 };
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_PLAIN_F32 = 2,
+       EPI_DGRAD_BN = 3,   // persistent kernel: data gradient + BN/ReLU backward of the layer below (GemmNTArgs::coef) against R
+       EPI_DGRAD_ST = 4 }; // persistent kernel: data gradient (+ dropout mask) + BN-backward sums against R
 
 struct GemmNTArgs {
     const void* A;       // [M][lda] T

@@ -123,6 +123,117 @@ __device__ __forceinline__ void nt256p_convert(const GemmNTArgs& a, f32x16 (&acc
     }
 }
 
+// ---- epilogues that work against the saved activation R (EPI_DGRAD_BN, EPI_DGRAD_ST) -------------------------------
+// The R tile (256 x 256 bf16 = 128 KiB) comes through the ring buffer that the finished K loop has just released
+// (64 KiB; the other one already holds the next tile's first stage), a QUARTER at a time: sub-tile column half i x sample
+// tiles {2jp, 2jp+1} of both sample halves = 128 rows x 128 features = 32 KiB, two quarters in flight (LDS-DMA, no
+// registers), so a quarter's fetch hides behind the previous quarter's arithmetic and stores.
+// Quarter image: local row lr = ws*64 + (jj&1)*32 + r, 256 bytes per row = 16 granules of 8 features, granule g = wf*4 + q
+// stored at physical granule g ^ (lr & 15) (the swizzle is applied to the DMA's per-lane SOURCE; an ds_read_b64 of a
+// wave then meets each bank pair twice instead of 32 times).
+template <int MT>
+__device__ __forceinline__ void nt256p_issue_quarter(const GemmNTArgs& a, int64_t m0, int f0, int i, int jp, uint32_t q_lds,
+                                                     int wave_u, int lane) {
+    const bf16_t* Rg = (const bf16_t*)a.R;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = wave_u * 4 + t;                                 // DMA instruction 0..31 = local rows 4k..4k+3
+        const int lr = 4 * k + (lane >> 4);
+        const int g = (lane & 15) ^ (lr & 15);
+        int64_t m = m0 + (lr >> 6) * (32 * MT) + jp * 64 + (lr & 63);
+        if (m >= a.M) m = a.M - 1;
+        glds16(Rg + m * a.ldr + f0 + (g >> 2) * 64 + i * 32 + (g & 3) * 8, q_lds + k * 1024);
+    }
+}
+
+// arithmetic + stores of one quarter; I, JP compile-time (they index the accumulator registers)
+template <int EPI, int MT, bool FULL, int I, int JP>
+__device__ __forceinline__ void nt256p_quarter(const GemmNTArgs& a, f32x16 (&acc)[2][MT], const unsigned char* Rq, const float* coef_s,
+                                               int64_t mw0, bf16_t* base, int fw0, int ws, int wf, int r, int h, uint32_t key,
+                                               float (&ps1)[16], float (&ps2)[16]) {
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+        constexpr int i = I;
+        const int jj = 2 * JP + j2;
+        const int64_t m = mw0 + jj * 32 + r;
+        const bool live = FULL || m < a.M;
+        const int lr = ws * 64 + j2 * 32 + r;
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint2 rr = *(const uint2*)(Rq + lr * 256 + (((wf * 4 + q) ^ (lr & 15)) << 4) + 8 * h);
+            const float r0 = __uint_as_float(rr.x << 16), r1 = __uint_as_float(rr.x & 0xffff0000u);
+            const float r2 = __uint_as_float(rr.y << 16), r3 = __uint_as_float(rr.y & 0xffff0000u);
+            float y0 = acc[i][jj][4 * q], y1 = acc[i][jj][4 * q + 1], y2 = acc[i][jj][4 * q + 2], y3 = acc[i][jj][4 * q + 3];
+            if constexpr (EPI == EPI_DGRAD_BN) {
+                const int fl = wf * 64 + i * 32 + 8 * q + 4 * h;
+                const float4 ca = *(const float4*)(coef_s + fl), cb = *(const float4*)(coef_s + 256 + fl), cz = *(const float4*)(coef_s + 512 + fl);
+                y0 = r0 > 0.f ? fmaf(ca.x, y0, fmaf(cb.x, r0, cz.x)) : 0.f;
+                y1 = r1 > 0.f ? fmaf(ca.y, y1, fmaf(cb.y, r1, cz.y)) : 0.f;
+                y2 = r2 > 0.f ? fmaf(ca.z, y2, fmaf(cb.z, r2, cz.z)) : 0.f;
+                y3 = r3 > 0.f ? fmaf(ca.w, y3, fmaf(cb.w, r3, cz.w)) : 0.f;
+            } else if (a.dp_thresh != 0) {
+                const uint32_t col = (uint32_t)(fw0 + i * 32 + 8 * q + 4 * h);      // column of y0 in the output row (even)
+                const uint32_t p0 = dropout_pair(key, (uint32_t)m, (uint32_t)a.ldc, col);
+                const uint32_t p1 = dropout_pair(key, (uint32_t)m, (uint32_t)a.ldc, col + 2);
+                y0 *= dropout_scale(p0, 0, a.dp_thresh, a.dp_inv_keep);
+                y1 *= dropout_scale(p0, 1, a.dp_thresh, a.dp_inv_keep);
+                y2 *= dropout_scale(p1, 0, a.dp_thresh, a.dp_inv_keep);
+                y3 *= dropout_scale(p1, 1, a.dp_thresh, a.dp_inv_keep);
+            }
+            pk[q].x = cvt_pk_bf16<false>(y0, y1);
+            pk[q].y = cvt_pk_bf16<false>(y2, y3);
+            // sums of the values as stored; rows past the end of a ragged tile do not count
+            float g0 = __uint_as_float(pk[q].x << 16), g1 = __uint_as_float(pk[q].x & 0xffff0000u);
+            float g2 = __uint_as_float(pk[q].y << 16), g3 = __uint_as_float(pk[q].y & 0xffff0000u);
+            if (!live) g0 = g1 = g2 = g3 = 0.f;
+            const int o = 4 * q;
+            ps1[o] += g0; ps1[o + 1] += g1; ps1[o + 2] += g2; ps1[o + 3] += g3;
+            if constexpr (EPI == EPI_DGRAD_ST) {
+                ps2[o] = fmaf(g0, r0, ps2[o]); ps2[o + 1] = fmaf(g1, r1, ps2[o + 1]);
+                ps2[o + 2] = fmaf(g2, r2, ps2[o + 2]); ps2[o + 3] = fmaf(g3, r3, ps2[o + 3]);
+            }
+            // keep the next quad's LDS reads (saved activation, coefficients) from being hoisted up here: with 128
+            // accumulator registers live, eight quads' worth of operands in flight is what made hipcc spill
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * kk].x, pk[2 * kk + 1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * kk].y, pk[2 * kk + 1].y, false, false);
+            const uint4 c = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            if (live) *(uint4*)(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk) = c;
+        }
+    }
+}
+
+// two DPP butterfly steps inside each quad of lanes: the 16 values of sub-tile half i -> 4 per statistic, accumulated over
+// tiles in qs[4i .. 4i+3]; the partial sums are cleared for the next half
+template <bool TWO>
+__device__ __forceinline__ void nt256p_fold_stats(float (&ps1)[16], float (&ps2)[16], int i, int lane, float (&qs1)[8], float (&qs2)[8]) {
+    const bool o0 = lane & 1, o1 = (lane >> 1) & 1;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const float k1 = o0 ? ps1[2 * p + 1] : ps1[2 * p], g1 = o0 ? ps1[2 * p] : ps1[2 * p + 1];
+        ps1[p] = k1 + dpp_quad<0xB1>(g1);
+        if constexpr (TWO) {
+            const float k2 = o0 ? ps2[2 * p + 1] : ps2[2 * p], g2 = o0 ? ps2[2 * p] : ps2[2 * p + 1];
+            ps2[p] = k2 + dpp_quad<0xB1>(g2);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float k1 = o1 ? ps1[2 * p + 1] : ps1[2 * p], g1 = o1 ? ps1[2 * p] : ps1[2 * p + 1];
+        qs1[4 * i + p] += k1 + dpp_quad<0x4E>(g1);
+        if constexpr (TWO) {
+            const float k2 = o1 ? ps2[2 * p + 1] : ps2[2 * p], g2 = o1 ? ps2[2 * p] : ps2[2 * p + 1];
+            qs2[4 * i + p] += k2 + dpp_quad<0x4E>(g2);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) ps1[v] = ps2[v] = 0.f;
+}
+
 // MT = 32-row sample tiles per wave: the block's tile is (64 * MT) x 256.  Measured at 167,936 x 512 x 512:
 // MT = 3 (7 rounds of 192 rows instead of 6 of 256: 12.5 % fewer padded rows) ran no faster, its 30 % more
 // weight-tile refills cost what the rounding saved; holding a converted 192-row tile in 48 registers to
@@ -134,7 +245,9 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     constexpr int BM = 64 * MT, BN = 256, BK = 64, EPC = 8;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + W_BYTES;
-    constexpr int LDS_BYTES = 2 * STAGE + 4 * BN * 4 + BN * 4;       // ring + [which][ws][BN] sums + bias
+    constexpr int LDS_BYTES = 2 * STAGE + 4 * BN * 4 + 3 * BN * 4;   // ring + [which][ws][BN] sums + bias / [3][BN] coefficients
+    constexpr bool RMODE = (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_ST);
+    static_assert(!RMODE || MT == 4, "the R epilogues are written for 256-row tiles");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     float* red = (float*)(smem + 2 * STAGE);
@@ -191,6 +304,10 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
 
     const int nk = a.K / BK;
     if (EPI == EPI_FWD && tid < BN) bias_s[tid] = a.bias[f0 + tid];
+    if (EPI == EPI_DGRAD_BN) {
+        for (int q = tid; q < 3 * BN; q += 512) bias_s[q] = a.coef[(q / BN) * a.coef_mod + (f0 + q % BN) % a.coef_mod];
+    }
+    const uint32_t dkey = (EPI == EPI_DGRAD_ST && a.dp_thresh != 0) ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -259,7 +376,50 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             buf ^= 1;
         }
 
-        {
+        if constexpr (RMODE) {
+            // quarters Q0..Q3 = (i, jp) = (0,0) (0,1) (1,0) (1,1); two 32 KiB halves of the released ring buffer take them in
+            // turn.  Waits are counted: vmcnt retires in issue order, so "all but the N youngest" leaves a quarter's 4 stores
+            // and the NEXT quarter's 4 DMAs in flight while guaranteeing the quarter about to be read has landed (a ragged
+            // tile, whose row-masked stores may be skipped, waits for everything instead; it is always a block's last tile).
+            // One instantiation with row masks serves both: a second, mask-free copy of this code cost registers.
+            // The epilogue's per-lane index arithmetic (16 DMA sources, LDS offsets, store addresses) is tile-invariant;
+            // hoisted out of the tile loop it would sit in ~60 registers through the K loop and spill.  An opaque zero,
+            // re-read every tile, keeps it inside the epilogue (a few dozen integer instructions per tile).
+            int zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+            const int lane = (tid & 63) + zero, r = lane & 31, h = lane >> 5;
+            const int64_t mw0 = m0 + ws * (BM / 2);
+            const int fw0 = f0 + wf * 64;
+            T* base = Cg + (mw0 + r) * a.ldc + fw0 + 8 * h;
+            const unsigned char* Rlo = smem + (buf ^ 1) * STAGE;
+            const unsigned char* Rhi = Rlo + 32768;
+            const uint32_t lo = lds0 + (buf ^ 1) * STAGE, hi = lo + 32768;
+            const bool full = m0 + BM <= a.M;
+            float ps1[16], ps2[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) ps1[v] = ps2[v] = 0.f;
+            nt256p_issue_quarter<MT>(a, m0, f0, 0, 0, lo, wave_u, lane);
+            nt256p_issue_quarter<MT>(a, m0, f0, 0, 1, hi, wave_u, lane);
+            if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            nt256p_quarter<EPI, MT, false, 0, 0>(a, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, dkey, ps1, ps2);
+            __syncthreads();                                                     // lo has been read by every wave
+            nt256p_issue_quarter<MT>(a, m0, f0, 1, 0, lo, wave_u, lane);
+            if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            nt256p_quarter<EPI, MT, false, 0, 1>(a, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, dkey, ps1, ps2);
+            nt256p_fold_stats<EPI == EPI_DGRAD_ST>(ps1, ps2, 0, lane, qs1, qs2);
+            __syncthreads();                                                     // hi has been read by every wave
+            nt256p_issue_quarter<MT>(a, m0, f0, 1, 1, hi, wave_u, lane);
+            if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            nt256p_quarter<EPI, MT, false, 1, 0>(a, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, dkey, ps1, ps2);
+            if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            nt256p_quarter<EPI, MT, false, 1, 1>(a, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, dkey, ps1, ps2);
+            nt256p_fold_stats<EPI == EPI_DGRAD_ST>(ps1, ps2, 1, lane, qs1, qs2);
+            if (has_next) __syncthreads();                                       // the next tile's second stage goes into this buffer
+        } else {
             const int64_t mw0 = m0 + ws * (BM / 2);
             T* base = Cg + (mw0 + r) * a.ldc + f0 + wf * 64 + 8 * h;
             if (m0 + BM > a.M) nt256p_convert<EPI, MT, false>(a, acc, mw0, base, r, lane, qs1, qs2);
@@ -269,7 +429,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
         tile_m = next_m;
     }
 
-    if constexpr (EPI == EPI_FWD) {
+    if constexpr (EPI == EPI_FWD || RMODE) {
         // remaining butterfly steps (lane bits 2..4), once per block
 #pragma unroll
         for (int s = 2, n = 8; s < 5; ++s, n >>= 1) {
@@ -289,7 +449,12 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
         __syncthreads();
         const int which = tid / BN, col = tid % BN;
         const int64_t prow = (int64_t)jm * 8 + xcd;
-        a.partials[(prow * 2 + which) * a.F + f0 + col] = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
+        const float v = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
+        if constexpr (EPI == EPI_DGRAD_BN) {
+            if (which == 0) a.partials[prow * a.F + f0 + col] = v;          // bias gradient of the layer below: rows of F
+        } else {
+            a.partials[(prow * 2 + which) * a.F + f0 + col] = v;
+        }
     }
 }
 

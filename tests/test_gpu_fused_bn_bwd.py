@@ -47,3 +47,40 @@ def test_bf16_fused_bn_backward_equals_separate_pass(dp, monkeypatch):
         cos = float(a @ b / (a.norm() * b.norm()))
         rel = float((a - b).norm() / b.norm())
         assert cos > 0.9995 and rel < 3e-2, (k, cos, rel)
+
+
+@pytest.mark.parametrize("dp", [0.0, 0.0635])
+def test_persistent_r_epilogue_equals_staged_r_epilogue(dp, monkeypatch):
+    """The data-gradient launches that work against the saved activation run in the persistent kernel (the R tile
+    arrives by LDS-DMA a quarter at a time; register-direct stores) -- against the same launches in the one-tile-per-block
+    kernel with its LDS-staged epilogue (CPNATIVE_STAGED_R_EPILOGUE).  Same dropout keys, so the masks are identical; the
+    staged epilogue rounds the gradient to bf16 once more before the mask / the BN arithmetic."""
+    from contrastiveprosthetics_amd.engine import Engine
+    n = 40000 - 40000 % T
+    g = torch.Generator().manual_seed(4)
+    mu = torch.randn(T, 12, generator=g)
+    x = (mu[None] + torch.randn(n // T, T, 12, generator=g)).reshape(n, 12).cuda()
+    labels = torch.arange(T).repeat(n // T).cuda()
+    grads = []
+    for staged in (False, True):
+        if staged:
+            monkeypatch.setenv("CPNATIVE_STAGED_R_EPILOGUE", "1")
+        else:
+            monkeypatch.delenv("CPNATIVE_STAGED_R_EPILOGUE", raising=False)
+        e = Engine(adabn=False, dtype="bf16", dp_emg=dp, device="cuda", seed=123)
+        e.init_parameters(6)
+        e.grads.flat.zero_()
+        z = e.encoder_forward(x, training=True)
+        e.head(z, labels, 1, want_grad=True)
+        e.encoder_backward(x)
+        torch.cuda.synchronize()
+        assert torch.isfinite(e.grads.flat).all()
+        grads.append({k: e.grads.views[k].clone() for k in e.specs})
+    for k in grads[0]:
+        a, b = grads[0][k].double().flatten(), grads[1][k].double().flatten()
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos = float(a @ b / (a.norm() * b.norm()))
+        rel = float((a - b).norm() / b.norm())
+        assert cos > 0.9995 and rel < 3e-2, (k, cos, rel)
