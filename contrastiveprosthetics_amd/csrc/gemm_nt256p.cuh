@@ -37,6 +37,9 @@ __device__ __forceinline__ float dpp_quad(float w) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w), CTRL, 0xF, 0xF, true));
 }
 
+// one 16-byte chunk of C.  (Non-temporal stores were measured: 203 vs 143 us forward, 195 vs 131 us data gradient --
+// the four chunks of a 128-byte line no longer merge in L2.)
+__device__ __forceinline__ void store_c16(bf16_t* p, const uint4& c) { *(uint4*)p = c; }
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
@@ -96,7 +99,7 @@ __device__ __forceinline__ void nt256p_convert(const GemmNTArgs& a, f32x16 (&acc
                 const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * kk].y, pk[2 * kk + 1].y, false, false);
                 // lanes 0..31: features 16kk..16kk+7 of row r; lanes 32..63: features 16kk+8..16kk+15
                 const uint4 c = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                if (live) *(uint4*)(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk) = c;
+                if (live) store_c16(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk, c);
             }
         }
     }
@@ -202,7 +205,7 @@ __device__ __forceinline__ void nt256p_quarter(const GemmNTArgs& a, f32x16 (&acc
             const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * kk].x, pk[2 * kk + 1].x, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * kk].y, pk[2 * kk + 1].y, false, false);
             const uint4 c = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-            if (live) *(uint4*)(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk) = c;
+            if (live) store_c16(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk, c);
         }
     }
 }
