@@ -126,45 +126,57 @@ __device__ __forceinline__ void nt256p_convert(const GemmNTArgs& a, f32x16 (&acc
     }
 }
 
+// sum over the 4 lanes of a quad of four per-lane values v0..v3 (two DPP butterfly steps): lane (b1 b0) of the quad ends
+// with the quad's total of v[2*b1 + b0] -- the first two steps of the 32-lane reduction of the BatchNorm column sums
+__device__ __forceinline__ float quad_fold(float v0, float v1, float v2, float v3, bool o0, bool o1) {
+    const float a = (o0 ? v1 : v0) + dpp_quad<0xB1>(o0 ? v0 : v1);       // quad_perm [1,0,3,2]
+    const float b = (o0 ? v3 : v2) + dpp_quad<0xB1>(o0 ? v2 : v3);
+    return (o1 ? b : a) + dpp_quad<0x4E>(o1 ? a : b);                    // quad_perm [2,3,0,1]
+}
+
 // ---- epilogues that work against the saved activation R (EPI_DGRAD_BN, EPI_DGRAD_ST) -------------------------------
 // The R tile (256 x 256 bf16 = 128 KiB) comes through the ring buffer that the finished K loop has just released
-// (64 KiB; the other one already holds the next tile's first stage), a QUARTER at a time: sub-tile column half i x sample
-// tiles {2jp, 2jp+1} of both sample halves = 128 rows x 128 features = 32 KiB, two quarters in flight (LDS-DMA, no
-// registers), so a quarter's fetch hides behind the previous quarter's arithmetic and stores.
-// Quarter image: local row lr = ws*64 + (jj&1)*32 + r, 256 bytes per row = 16 granules of 8 features, granule g = wf*4 + q
-// stored at physical granule g ^ (lr & 15) (the swizzle is applied to the DMA's per-lane SOURCE; an ds_read_b64 of a
+// (64 KiB; the other one already holds the next tile's first stage), a QUARTER at a time: sample tile jj of both sample
+// halves x all 256 features = 64 rows x 512 bytes = 32 KiB, two quarters in flight (LDS-DMA, no registers), so a quarter's
+// fetch hides behind the previous quarter's arithmetic and stores.  A quarter holds whole output rows, so a wave still
+// writes the four 16-byte chunks of a row's 128-byte line back to back (L2 merges them only then: splitting a line
+// over two quarters showed 8-25 % more bytes written in the PMC pass).
+// Quarter image: local row lr = ws*32 + r, 512 bytes per row = 32 granules of 8 features, granule g = wf*8 + i*4 + q
+// stored at physical granule g ^ (lr & 31) (the swizzle is applied to the DMA's per-lane SOURCE; a ds_read_b64 of a
 // wave then meets each bank pair twice instead of 32 times).
 template <int MT>
-__device__ __forceinline__ void nt256p_issue_quarter(const GemmNTArgs& a, int64_t m0, int f0, int i, int jp, uint32_t q_lds,
+__device__ __forceinline__ void nt256p_issue_quarter(const GemmNTArgs& a, int64_t m0, int f0, int jj, uint32_t q_lds,
                                                      int wave_u, int lane) {
     const bf16_t* Rg = (const bf16_t*)a.R;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int k = wave_u * 4 + t;                                 // DMA instruction 0..31 = local rows 4k..4k+3
-        const int lr = 4 * k + (lane >> 4);
-        const int g = (lane & 15) ^ (lr & 15);
-        int64_t m = m0 + (lr >> 6) * (32 * MT) + jp * 64 + (lr & 63);
+        const int k = wave_u * 4 + t;                                 // DMA instruction 0..31 = local rows 2k, 2k+1
+        const int lr = 2 * k + (lane >> 5);
+        const int g = (lane & 31) ^ (lr & 31);
+        int64_t m = m0 + (lr >> 5) * (32 * MT) + jj * 32 + (lr & 31);
         if (m >= a.M) m = a.M - 1;
-        glds16(Rg + m * a.ldr + f0 + (g >> 2) * 64 + i * 32 + (g & 3) * 8, q_lds + k * 1024);
+        glds16(Rg + m * a.ldr + f0 + g * 8, q_lds + k * 1024);
     }
 }
 
-// arithmetic + stores of one quarter; I, JP compile-time (they index the accumulator registers)
-template <int EPI, int MT, bool FULL, int I, int JP>
+// arithmetic + stores of one quarter (sample tile JJ of this wave, both feature halves); JJ compile-time (it indexes the
+// accumulator registers).  The statistics of each feature half are folded into qs right away (one 16-value scratch set).
+template <int EPI, int MT, int JJ>
 __device__ __forceinline__ void nt256p_quarter(const GemmNTArgs& a, f32x16 (&acc)[2][MT], const unsigned char* Rq, const float* coef_s,
-                                               int64_t mw0, bf16_t* base, int fw0, int ws, int wf, int r, int h, uint32_t key,
-                                               float (&ps1)[16], float (&ps2)[16]) {
+                                               int64_t mw0, bf16_t* base, int fw0, int ws, int wf, int r, int h, int lane, uint32_t key,
+                                               float (&qs1)[8], float (&qs2)[8]) {
+    constexpr int jj = JJ;
+    const int64_t m = mw0 + jj * 32 + r;
+    const bool live = m < a.M;
+    const int lr = ws * 32 + r;
+    const bool o0 = lane & 1, o1 = (lane >> 1) & 1;
+    uint4 out[2][2];
 #pragma unroll
-    for (int j2 = 0; j2 < 2; ++j2) {
-        constexpr int i = I;
-        const int jj = 2 * JP + j2;
-        const int64_t m = mw0 + jj * 32 + r;
-        const bool live = FULL || m < a.M;
-        const int lr = ws * 64 + j2 * 32 + r;
+    for (int i = 0; i < 2; ++i) {
         uint2 pk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint2 rr = *(const uint2*)(Rq + lr * 256 + (((wf * 4 + q) ^ (lr & 15)) << 4) + 8 * h);
+            const uint2 rr = *(const uint2*)(Rq + lr * 512 + (((wf * 8 + i * 4 + q) ^ (lr & 31)) << 4) + 8 * h);
             const float r0 = __uint_as_float(rr.x << 16), r1 = __uint_as_float(rr.x & 0xffff0000u);
             const float r2 = __uint_as_float(rr.y << 16), r3 = __uint_as_float(rr.y & 0xffff0000u);
             float y0 = acc[i][jj][4 * q], y1 = acc[i][jj][4 * q + 1], y2 = acc[i][jj][4 * q + 2], y3 = acc[i][jj][4 * q + 3];
@@ -190,12 +202,8 @@ __device__ __forceinline__ void nt256p_quarter(const GemmNTArgs& a, f32x16 (&acc
             float g0 = __uint_as_float(pk[q].x << 16), g1 = __uint_as_float(pk[q].x & 0xffff0000u);
             float g2 = __uint_as_float(pk[q].y << 16), g3 = __uint_as_float(pk[q].y & 0xffff0000u);
             if (!live) g0 = g1 = g2 = g3 = 0.f;
-            const int o = 4 * q;
-            ps1[o] += g0; ps1[o + 1] += g1; ps1[o + 2] += g2; ps1[o + 3] += g3;
-            if constexpr (EPI == EPI_DGRAD_ST) {
-                ps2[o] = fmaf(g0, r0, ps2[o]); ps2[o + 1] = fmaf(g1, r1, ps2[o + 1]);
-                ps2[o + 2] = fmaf(g2, r2, ps2[o + 2]); ps2[o + 3] = fmaf(g3, r3, ps2[o + 3]);
-            }
+            qs1[4 * i + q] += quad_fold(g0, g1, g2, g3, o0, o1);
+            if constexpr (EPI == EPI_DGRAD_ST) qs2[4 * i + q] += quad_fold(g0 * r0, g1 * r1, g2 * r2, g3 * r3, o0, o1);
             // keep the next quad's LDS reads (saved activation, coefficients) from being hoisted up here: with 128
             // accumulator registers live, eight quads' worth of operands in flight is what made hipcc spill
             asm volatile("" ::: "memory");
@@ -204,37 +212,24 @@ __device__ __forceinline__ void nt256p_quarter(const GemmNTArgs& a, f32x16 (&acc
         for (int kk = 0; kk < 2; ++kk) {
             const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * kk].x, pk[2 * kk + 1].x, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * kk].y, pk[2 * kk + 1].y, false, false);
-            const uint4 c = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-            if (live) store_c16(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk, c);
+            out[i][kk] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+        if constexpr (EPI == EPI_DGRAD_ST) {
+            // (this mode also carries the second statistic and the dropout hashes: holding both halves' chunks spilled;
+            //  its two half-lines leave a few hundred cycles apart, from the same wave)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                if (live) store_c16(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk, out[i][kk]);
         }
     }
-}
-
-// two DPP butterfly steps inside each quad of lanes: the 16 values of sub-tile half i -> 4 per statistic, accumulated over
-// tiles in qs[4i .. 4i+3]; the partial sums are cleared for the next half
-template <bool TWO>
-__device__ __forceinline__ void nt256p_fold_stats(float (&ps1)[16], float (&ps2)[16], int i, int lane, float (&qs1)[8], float (&qs2)[8]) {
-    const bool o0 = lane & 1, o1 = (lane >> 1) & 1;
+    if constexpr (EPI != EPI_DGRAD_ST) {
+        // the row's four chunks leave together
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const float k1 = o0 ? ps1[2 * p + 1] : ps1[2 * p], g1 = o0 ? ps1[2 * p] : ps1[2 * p + 1];
-        ps1[p] = k1 + dpp_quad<0xB1>(g1);
-        if constexpr (TWO) {
-            const float k2 = o0 ? ps2[2 * p + 1] : ps2[2 * p], g2 = o0 ? ps2[2 * p] : ps2[2 * p + 1];
-            ps2[p] = k2 + dpp_quad<0xB1>(g2);
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                if (live) store_c16(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk, out[i][kk]);
     }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float k1 = o1 ? ps1[2 * p + 1] : ps1[2 * p], g1 = o1 ? ps1[2 * p] : ps1[2 * p + 1];
-        qs1[4 * i + p] += k1 + dpp_quad<0x4E>(g1);
-        if constexpr (TWO) {
-            const float k2 = o1 ? ps2[2 * p + 1] : ps2[2 * p], g2 = o1 ? ps2[2 * p] : ps2[2 * p + 1];
-            qs2[4 * i + p] += k2 + dpp_quad<0x4E>(g2);
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < 16; ++v) ps1[v] = ps2[v] = 0.f;
 }
 
 // MT = 32-row sample tiles per wave: the block's tile is (64 * MT) x 256.  Measured at 167,936 x 512 x 512:
@@ -380,7 +375,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
         }
 
         if constexpr (RMODE) {
-            // quarters Q0..Q3 = (i, jp) = (0,0) (0,1) (1,0) (1,1); two 32 KiB halves of the released ring buffer take them in
+            // four quarters (sample tiles jj = 0..3); two 32 KiB halves of the released ring buffer take them in
             // turn.  Waits are counted: vmcnt retires in issue order, so "all but the N youngest" leaves a quarter's 4 stores
             // and the NEXT quarter's 4 DMAs in flight while guaranteeing the quarter about to be read has landed (a ragged
             // tile, whose row-masked stores may be skipped, waits for everything instead; it is always a block's last tile).
@@ -398,29 +393,24 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             const unsigned char* Rhi = Rlo + 32768;
             const uint32_t lo = lds0 + (buf ^ 1) * STAGE, hi = lo + 32768;
             const bool full = m0 + BM <= a.M;
-            float ps1[16], ps2[16];
-#pragma unroll
-            for (int v = 0; v < 16; ++v) ps1[v] = ps2[v] = 0.f;
-            nt256p_issue_quarter<MT>(a, m0, f0, 0, 0, lo, wave_u, lane);
-            nt256p_issue_quarter<MT>(a, m0, f0, 0, 1, hi, wave_u, lane);
+            nt256p_issue_quarter<MT>(a, m0, f0, 0, lo, wave_u, lane);
+            nt256p_issue_quarter<MT>(a, m0, f0, 1, hi, wave_u, lane);
             if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            nt256p_quarter<EPI, MT, false, 0, 0>(a, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, dkey, ps1, ps2);
+            nt256p_quarter<EPI, MT, 0>(a, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
             __syncthreads();                                                     // lo has been read by every wave
-            nt256p_issue_quarter<MT>(a, m0, f0, 1, 0, lo, wave_u, lane);
+            nt256p_issue_quarter<MT>(a, m0, f0, 2, lo, wave_u, lane);
             if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            nt256p_quarter<EPI, MT, false, 0, 1>(a, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, dkey, ps1, ps2);
-            nt256p_fold_stats<EPI == EPI_DGRAD_ST>(ps1, ps2, 0, lane, qs1, qs2);
+            nt256p_quarter<EPI, MT, 1>(a, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
             __syncthreads();                                                     // hi has been read by every wave
-            nt256p_issue_quarter<MT>(a, m0, f0, 1, 1, hi, wave_u, lane);
+            nt256p_issue_quarter<MT>(a, m0, f0, 3, hi, wave_u, lane);
             if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            nt256p_quarter<EPI, MT, false, 1, 0>(a, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, dkey, ps1, ps2);
+            nt256p_quarter<EPI, MT, 2>(a, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
             if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            nt256p_quarter<EPI, MT, false, 1, 1>(a, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, dkey, ps1, ps2);
-            nt256p_fold_stats<EPI == EPI_DGRAD_ST>(ps1, ps2, 1, lane, qs1, qs2);
+            nt256p_quarter<EPI, MT, 3>(a, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
             if (has_next) __syncthreads();                                       // the next tile's second stage goes into this buffer
         } else {
             const int64_t mw0 = m0 + ws * (BM / 2);
