@@ -215,8 +215,9 @@ __device__ __forceinline__ void nt256p_quarter(const GemmNTArgs& a, f32x16 (&acc
             out[i][kk] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
         if constexpr (EPI == EPI_DGRAD_ST) {
-            // (this mode also carries the second statistic and the dropout hashes: holding both halves' chunks spilled;
-            //  its two half-lines leave a few hundred cycles apart, from the same wave)
+            // (this mode also carries the second statistic and the dropout hashes: holding both halves' chunks spills 15
+            //  registers and measured slower; its two half-lines leave a few hundred cycles apart, from the same wave:
+            //  180 MB written per 172 MB of output)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
                 if (live) store_c16(base + (int64_t)(jj * 32) * a.ldc + i * 32 + 16 * kk, out[i][kk]);
@@ -310,10 +311,10 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // BatchNorm column sums carried across the block's tiles: value v = 4p + (lane & 3), v = i*16 + 4q + e
-    float qs1[8], qs2[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) qs1[p] = qs2[p] = 0.f;
+    // column sums carried across the block's tiles: ONE value per lane and statistic (the tile's 32-lane reduction is
+    // finished every tile: 7 extra shuffles per statistic, and 14 registers fewer through the K loop than carrying the
+    // half-reduced sums).  Lane r of half h holds value r = i*16 + 4q + e.
+    float tot1 = 0.f, tot2 = 0.f;
     T* Cg = (T*)a.C;
     int buf = 0;
 
@@ -374,6 +375,9 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             buf ^= 1;
         }
 
+        float qs1[8], qs2[8];                                  // this tile's sums after the two quad steps: value 4p + (lane & 3)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) qs1[p] = qs2[p] = 0.f;
         if constexpr (RMODE) {
             // four quarters (sample tiles jj = 0..3); two 32 KiB halves of the released ring buffer take them in
             // turn.  Waits are counted: vmcnt retires in issue order, so "all but the N youngest" leaves a quarter's 4 stores
@@ -418,27 +422,33 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             if (m0 + BM > a.M) nt256p_convert<EPI, MT, false>(a, acc, mw0, base, r, lane, qs1, qs2);
             else nt256p_convert<EPI, MT, true>(a, acc, mw0, base, r, lane, qs1, qs2);
         }
+        if constexpr (EPI == EPI_FWD || RMODE) {
+            // remaining butterfly steps (lane bits 2..4)
+#pragma unroll
+            for (int s = 2, n = 8; s < 5; ++s, n >>= 1) {
+                const bool odd = (lane >> s) & 1;
+#pragma unroll
+                for (int p = 0; p < n / 2; ++p) {
+                    const float k1 = odd ? qs1[2 * p + 1] : qs1[2 * p], g1 = odd ? qs1[2 * p] : qs1[2 * p + 1];
+                    qs1[p] = k1 + __shfl_xor(g1, 1 << s, 64);
+                    if constexpr (EPI != EPI_DGRAD_BN) {
+                        const float k2 = odd ? qs2[2 * p + 1] : qs2[2 * p], g2 = odd ? qs2[2 * p] : qs2[2 * p + 1];
+                        qs2[p] = k2 + __shfl_xor(g2, 1 << s, 64);
+                    }
+                }
+            }
+            tot1 += qs1[0];
+            tot2 += qs2[0];
+        }
         if (!has_next) break;
         tile_m = next_m;
     }
 
     if constexpr (EPI == EPI_FWD || RMODE) {
-        // remaining butterfly steps (lane bits 2..4), once per block
-#pragma unroll
-        for (int s = 2, n = 8; s < 5; ++s, n >>= 1) {
-            const bool odd = (lane >> s) & 1;
-#pragma unroll
-            for (int p = 0; p < n / 2; ++p) {
-                const float k1 = odd ? qs1[2 * p + 1] : qs1[2 * p], g1 = odd ? qs1[2 * p] : qs1[2 * p + 1];
-                const float k2 = odd ? qs2[2 * p + 1] : qs2[2 * p], g2 = odd ? qs2[2 * p] : qs2[2 * p + 1];
-                qs1[p] = k1 + __shfl_xor(g1, 1 << s, 64);
-                qs2[p] = k2 + __shfl_xor(g2, 1 << s, 64);
-            }
-        }
         // lane r of half h holds value r = i*16 + 4q + e  ->  feature wf*64 + i*32 + 8q + 4h + e
         const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
-        red[(0 * 2 + ws) * BN + fl] = qs1[0];
-        red[(1 * 2 + ws) * BN + fl] = qs2[0];
+        red[(0 * 2 + ws) * BN + fl] = tot1;
+        red[(1 * 2 + ws) * BN + fl] = tot2;
         __syncthreads();
         const int which = tid / BN, col = tid % BN;
         const int64_t prow = (int64_t)jm * 8 + xcd;
