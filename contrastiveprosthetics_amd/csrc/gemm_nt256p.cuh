@@ -342,8 +342,6 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
         }
 
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-            else if (has_next) { set_src(next_m); stage(buf ^ 1, 0); }
             const unsigned char* As = smem + buf * STAGE;
             const unsigned char* Ws = As + A_BYTES;
             uint4 fw[2][2], fs[2][MT];
@@ -351,6 +349,11 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             for (int i = 0; i < 2; ++i) fw[0][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, h));
 #pragma unroll
             for (int jj = 0; jj < MT; ++jj) fs[0][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, h));
+            // the next stage's DMA requests go out while the first fragments are on their way from LDS (issued before those
+            // reads: +1 % step time; behind the first MFMA group: +3 %)
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+            else if (has_next) { set_src(next_m); stage(buf ^ 1, 0); }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
