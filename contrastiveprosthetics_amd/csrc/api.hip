@@ -774,6 +774,8 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     T* dz = (T*)(base + w.dz);
     T* cur = (T*)(base + w.gbuf[0]);
     T* nxt = (T*)(base + w.gbuf[1]);
+    bool bn_done = false;           // (see the comment above the fc loop)
+    const bool fuse_ok = sizeof(T) == 2 && !getenv("CPNATIVE_UNFUSED_BN_BWD");
     // ---- projection ------------------------------------------------------------------
     {
         ProfScope ps(CP_K_PROJ_BWD, st);
@@ -809,8 +811,24 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         a.C = cur; a.ldc = 512; a.R = drop ? act(8) : nullptr; a.ldr = 512; a.partials = partials;
         if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         int drows = 0;
-        CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
-        if (drop) stat_rows = drows;                 // partial rows of BN-backward sums written by this launch
+        if (fuse_ok && !drop) {
+            // no dropout behind fc7: its BN-backward sums are known (from the projection's weight gradient), so this
+            // launch applies fc7's BN + ReLU backward itself, as the fc launches below do for their layer below
+            int nr = stat_rows;
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(FIN_THREADS), 0, st, partials, nr, (double)N, stats(8), coef,
+                               g->bn_g[8], g->bn_b[8], 512, 1);
+            CKL("bn_bwd_finalize_kernel(fc7, fused)");
+            a.R = act(8); a.coef = coef; a.coef_mod = 512;
+            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
+            nr = drows;
+            const float* pp = pre(nr, 512);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(512 / 64), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[6]);
+            CKL("colsum_finalize_kernel(fc7, fused)");
+            bn_done = true;
+        } else {
+            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
+            if (drop) stat_rows = drows;             // partial rows of BN-backward sums written by this launch
+        }
     }
     // ---- fc7 .. fc1 --------------------------------------------------------------------
     // bn_done: BatchNorm + ReLU backward of layer L were applied by the data-gradient launch of the layer above (its
@@ -818,8 +836,6 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     // bf16 only, and only where no dropout sits between the layers (the coefficients must exist before the launch:
     // they do when the BN-backward sums come from the weight gradient).  CPNATIVE_UNFUSED_BN_BWD (read per call)
     // keeps the separate pass, for the test that compares the two orders.
-    bool bn_done = false;
-    const bool fuse_ok = sizeof(T) == 2 && !getenv("CPNATIVE_UNFUSED_BN_BWD");
     for (int L = 8; L >= 2; --L) {
         const int i = L - 2, Lp = L - 1, K = fcK(i);
         if (!bn_done) {
