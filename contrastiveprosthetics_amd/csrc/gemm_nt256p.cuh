@@ -27,7 +27,14 @@
 // Also measured: staging through registers (global_load_dwordx4 at the start of a K step, ds_write_b128 at its end)
 // to avoid the LDS-DMA issue cost (8 issues per wave per K step, 100-185 cycles each beside ds_reads and MFMAs).  With
 // 128 accumulator + 48 fragment registers live there is no room for the 32 staging registers: hipcc parks them in
-// scratch right after the loads (a vmcnt wait + scratch_store per load), 338 us against 131 us.
+// scratch right after the loads (a vmcnt wait + scratch_store per load), 338 us against 131 us.  Once the column sums
+// stopped being carried through the K loop there was room for HALF a stage (the A rows, 16 registers as four scalar
+// uint4 -- an array of them still went to scratch): 4 LDS-DMA requests per wave and K step instead of 8, no scratch,
+// same speed (151.8 vs 149.2 us forward, 130.1 vs 128.1 us data gradient).  So the DMA issue cost is not what holds the
+// K loop back.  What the numbers say instead: a K step moves 64 KiB into LDS and 196 KiB out of it (24 fragment reads x
+// 8 waves); at the guide's LDS rates that is ~1,800 of the 2,048 cycles the step's MFMAs take on each SIMD pair -- the
+// loop is co-limited by LDS bandwidth and the matrix pipe, which leaves nothing to hide latencies behind.  Fewer LDS
+// bytes per MFMA needs 128 x 128 wave tiles (256 accumulator registers, one wave per SIMD): a different kernel.
 #pragma once
 #include "gemm_nt256.cuh"
 
