@@ -80,6 +80,7 @@ SYMBOLS = {
                                   C.c_int32, _P(cp_adam_hyper), C.c_int64, _fp, _fp, _fp]),
     "cp_l2_adam_step_graph": (C.c_int, [_fp, _fp, _fp, _fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32),
                                         C.c_int32, _P(cp_adam_hyper), _fp, _fp, _fp, _fp]),
+    "cp_debug_hog": (C.c_int, [C.c_int32, C.c_int32, _fp]),
     "cp_profile_enable": (C.c_int, [C.c_uint64, C.c_int32]),
     "cp_profile_disable": (C.c_int, []),
     "cp_profile_summary": (C.c_int, [C.c_int32, _P(C.c_double), _P(C.c_int64)]),

@@ -294,7 +294,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const int C = kLayerC[l];
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
         const float* pp = batch_stats ? pre(nrows, 2 * C) : partials;
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(FIN_THREADS), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
                            have_running ? bn->running_mean[l] : nullptr, have_running ? bn->running_var[l] : nullptr, upd,
                            batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats(l), C);
         hipError_t e = hipGetLastError();
@@ -605,7 +605,7 @@ static int glove_forward_t(const cp_config* c, const cp_glove_params* gp, const 
         int nrows = (int)((R + 127) / 128);
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
         const float* pp = batch_stats ? pre(nrows, 2 * GL_H) : partials;
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(GL_H / 64), dim3(FIN_THREADS), 0, st, pp, nrows, (double)R, gp->bn_g, gp->bn_b,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(GL_H)), dim3(FIN_THREADS), 0, st, pp, nrows, (double)R, gp->bn_g, gp->bn_b,
                            have_running ? gp->running_mean : nullptr, have_running ? gp->running_var : nullptr, upd,
                            batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats, GL_H);
         CKL("bn_finalize_kernel(glove)");
@@ -710,7 +710,7 @@ static int glove_backward_t(const cp_config* c, const cp_glove_params* gp, int64
         CKL("relu_bwd_colsum_kernel");
         int nr = gb;
         const float* pp = pre(nr, 2 * GL_H);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(GL_H / 64), dim3(FIN_THREADS), 0, st, pp, nr, (double)R, stats, coef, g->bn_g, g->bn_b, GL_H, 1);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(GL_H)), dim3(FIN_THREADS), 0, st, pp, nr, (double)R, stats, coef, g->bn_g, g->bn_b, GL_H, 1);
         CKL("bn_bwd_finalize_kernel(glove)");
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_rows(R * GL_H / D::EPC, 256, 4096)), dim3(256), 0, st, gbuf, h, coef, R, GL_H);
         CKL("bn_bwd_apply_kernel");
@@ -786,7 +786,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             s = stats(8) + 2 * 512; t = stats(8) + 3 * 512;
             const int gb = grid_rows(N, 256 / (CP_D_E / D::EPC), 64);
             hipLaunchKernelGGL((colsum_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, dz, partials, N, 64, CP_D_E);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, st, partials, gb, CP_D_E, dzsum);  // 16 columns: tiny
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(CP_D_E)), dim3(FIN_THREADS), 0, st, partials, gb, CP_D_E, dzsum);  // 16 columns: tiny
             CKL("colsum(dz)");
         }
         GemmTNArgs ta{};
@@ -815,14 +815,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // no dropout behind fc7: its BN-backward sums are known (from the projection's weight gradient), so this
             // launch applies fc7's BN + ReLU backward itself, as the fc launches below do for their layer below
             int nr = stat_rows;
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(FIN_THREADS), 0, st, partials, nr, (double)N, stats(8), coef,
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, partials, nr, (double)N, stats(8), coef,
                                g->bn_g[8], g->bn_b[8], 512, 1);
             CKL("bn_bwd_finalize_kernel(fc7, fused)");
             a.R = act(8); a.coef = coef; a.coef_mod = 512;
             CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
             nr = drows;
             const float* pp = pre(nr, 512);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(512 / 64), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[6]);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[6]);
             CKL("colsum_finalize_kernel(fc7, fused)");
             bn_done = true;
         } else {
@@ -842,14 +842,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;
             const float* pp = pre(nr, 2 * 512);
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(512 / 64), dim3(FIN_THREADS), 0, st, pp, nr, (double)N, stats(L), coef,
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, (double)N, stats(L), coef,
                                g->bn_g[L], g->bn_b[L], 512, 1);
             CKL("bn_bwd_finalize_kernel");
             const int gb = grid_rows(N, 256 / (512 / D::EPC), 2048);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
             nr = gb;
             pp = pre(nr, 512);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(512 / 64), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[i]);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[i]);
             CKL("bn_relu_bwd_kernel");
         }
         const bool in_drop = drop && Lp >= 5;
@@ -901,7 +901,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 ProfScope ps(CP_K_BN_BWD, st);
                 int nr = stat_rows;
                 const float* pp = pre(nr, 2 * K);
-                hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / 64), dim3(FIN_THREADS), 0, st, pp, nr, (double)N * nfold, stats(Lp), coef,
+                hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(Cp)), dim3(FIN_THREADS), 0, st, pp, nr, (double)N * nfold, stats(Lp), coef,
                                    g->bn_g[Lp], g->bn_b[Lp], Cp, nfold);
                 CKL("bn_bwd_finalize_kernel(fused)");
             }
@@ -916,7 +916,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 int nr = drows * nfold;                                   // rows of K = nfold rows of Cp
                 const float* pp = pre(nr, Cp);
                 float* db = Lp >= 2 ? g->fc_b[i - 1] : g->conv2_b;
-                hipLaunchKernelGGL(colsum_finalize_kernel, dim3(Cp / 64), dim3(FIN_THREADS), 0, st, pp, nr, Cp, db);
+                hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(Cp)), dim3(FIN_THREADS), 0, st, pp, nr, Cp, db);
                 CKL("colsum_finalize_kernel(fused)");
             }
             bn_done = true;
@@ -936,14 +936,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
             const float* pp = pre(nr, 2 * 768);
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(1), coef,
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(1), coef,
                                g->bn_g[1], g->bn_b[1], 64, 12);
             CKL("bn_bwd_finalize_kernel(conv2)");
             const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
             nr = gb;
             pp = pre(nr, 64);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
             CKL("bn_relu_bwd_kernel(conv2)");
         }
         ConvArgs ca{};
@@ -982,7 +982,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         ProfScope ps(CP_K_CONV1_BWD, st);
         int nr = conv_dgrad_rows;
         const float* pp = pre(nr, 2 * 64);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(0), coef, g->bn_g[0],
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(0), coef, g->bn_g[0],
                            g->bn_b[0], 64, 1);
         CKL("bn_bwd_finalize_kernel(conv1)");
         constexpr int RPP = 256 / (64 / D::EPC);
@@ -1155,6 +1155,20 @@ static int debug_gemm_t(int kind, int64_t M, int K, int F, const void* A, const 
     a.R = R; a.ldr = F; a.partials = partials; a.dbg = dbg;
     if (kind == 0) CK((launch_fc_gemm<T, EPI_FWD>(a, st)));
     else CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void hog_kernel(long long ticks, float* sink) {
+    __shared__ float pad[30 * 1024];                       // 120 KiB: no 64 KiB-stage GEMM block fits beside this one
+    pad[threadIdx.x] = (float)threadIdx.x;
+    const long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink && pad[threadIdx.x] < -1.f) *sink = pad[0];
+}
+extern "C" int cp_debug_hog(int32_t blocks, int32_t microseconds, void* stream) {
+    if (blocks <= 0 || microseconds <= 0 || microseconds > 100000) return fail(CP_ERR_ARG, "cp_debug_hog args");
+    hipLaunchKernelGGL(hog_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long long)microseconds * 100, (float*)nullptr);
+    CKL("hog_kernel");
     return 0;
 }
 

@@ -10,12 +10,21 @@
 // from the accumulator registers, no LDS staging, no barrier (see the register-direct epilogue in
 // gemm_nt256.cuh) -- drain underneath tile n+1's first K step.
 //
-// Tile schedule (XCD-aware): block b runs on XCD b & 7; with j = b >> 3, tile_f = j % tiles_f is
-// FIXED for the block and round n handles sample tile ((n * J/tiles_f + j / tiles_f) * 8 + xcd), so the
-// tiles_f blocks that share one A tile run it in the same round on the same XCD (second read = L2
-// hit).  A fixed tile_f also means the folded weights' rows, the bias and the BatchNorm column sums
-// are per-block constants: the sums are carried in registers across tiles and written as ONE
-// partial row per block (row = (j / tiles_f) * 8 + xcd).
+// Tile schedule (XCD-aware, dynamic): block b runs on XCD b & 7 and draws that XCD's tiles -- sample tile
+// (item / tiles_f) * 8 + xcd, column tile item % tiles_f -- from a per-XCD counter, one tile ahead of the one it
+// is computing.  Neighbouring items share an A tile and are drawn by different blocks at about the same time, so
+// its second read is an L2 hit.  The bias / BatchNorm coefficients of every column tile sit in LDS; the
+// BatchNorm column sums leave as ONE partial row per SAMPLE TILE (not per block), so the sums downstream add
+// up in the same order whichever block ran which tile: results do not depend on the schedule.
+// The first version of this kernel assigned tiles statically (block j of an XCD: fixed column tile, every
+// (J/tiles_f)-th sample tile, sums carried in registers, one partial row per block).  Alone on the GPU that ran
+// 2-4 % faster (145 / 180 / 170 us for the three fc launches against 148 / 185 / 176), but with 8-32 CUs held by
+// another stream's kernel -- RCCL at N > 1, a neighbour process in a packed hyper-parameter sweep -- the blocks
+// that start late hold the whole launch back: 202-208 us against 150, where this version stays at 150
+// (tools/contention_bench.py).
+// Also measured on top of the dynamic schedule: handing out the leftover round (164 tiles on an XCD's 32 CUs = 5
+// rounds + 4 tiles) in quarter tiles of 64 rows.  A quarter's K step has 8 MFMAs per wave to cover the same
+// stage latency, so it took well over half a tile's time: forward 154 us instead of 148.
 //
 // Measured and dropped on top of this kernel: applying the layer below's BatchNorm + ReLU backward in the
 // data-gradient epilogue (coefficients are known beforehand thanks to bn_bwd_sums_from_wgrad_kernel; the
@@ -39,7 +48,11 @@
 // measured 145 us against 127-132 us here, with the stage requests either spread behind the MFMAs or issued up front:
 // with a lone wave per SIMD nothing covers its LDS and barrier latencies, and hipcc's schedule does not either.
 #pragma once
+#include <mutex>
 #include "gemm_nt256.cuh"
+
+#define NT256P_MAX_TILES_F 3      // F <= 768: the encoder's widest data gradient
+#define NT256P_SCHED_SLOTS 64     // streams per process that may run this kernel
 
 // quad-permuted copy of w (DPP, no LDS crossbar)
 template <int CTRL>
@@ -254,25 +267,27 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     constexpr int BM = 64 * MT, BN = 256, BK = 64, EPC = 8;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + W_BYTES;
-    constexpr int LDS_BYTES = 2 * STAGE + 4 * BN * 4 + 3 * BN * 4;   // ring + [which][ws][BN] sums + bias / [3][BN] coefficients
+    constexpr int MAX_TF = NT256P_MAX_TILES_F;
     constexpr bool RMODE = (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_ST);
+    constexpr bool STATS = (EPI == EPI_FWD || RMODE);
+    // ring + [which][ws][BN] sums of one tile + per-column-tile bias / [3][BN] coefficients
+    constexpr int LDS_BYTES = 2 * STAGE + 4 * BN * 4 + MAX_TF * 3 * BN * 4;
     static_assert(!RMODE || MT == 4, "the R epilogues are written for 256-row tiles");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(LDS_BYTES <= 160 * 1024 - 64, "LDS");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    float* red = (float*)(smem + 2 * STAGE);
-    float* bias_s = red + 4 * BN;
+    __shared__ int s_item[2];
+    float* red = (float*)(smem + 2 * STAGE);             // [which][ws][BN]
+    float* bias_all = red + 4 * BN;                      // [tf][BN] or [tf][3][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int tiles_f = a.F / BN;
     const int64_t tiles_m = (a.M + BM - 1) / BM;
     const int xcd = blockIdx.x & 7;
-    const int j = blockIdx.x >> 3, J = gridDim.x >> 3;
-    const int tile_f = j % tiles_f, jm = j / tiles_f;
-    const int64_t stride_m = (int64_t)(J / tiles_f) * 8;
-    int64_t tile_m = (int64_t)jm * 8 + xcd;
-    if (tile_m >= tiles_m) return;
-    const int f0 = tile_f * BN;
+    // work items of this XCD, handed out by its counter: item -> sample tile (item / tiles_f) * 8 + xcd, column tile
+    // item % tiles_f, so the column tiles of one sample tile run at about the same time behind the same L2
+    const int items = xcd < tiles_m ? (int)((tiles_m - xcd + 7) / 8) * tiles_f : 0;
+    int* ctr = a.sched + xcd * 32;                       // a 128-byte line per counter
     const int ws = wave >> 2, wf = wave & 3;
 
     const T* __restrict__ Ag = (const T*)a.A;
@@ -280,23 +295,21 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     const int lrow = lane >> 3, pch = lane & 7;
     const T* asrc[MT];
     const T* wsrc[4];
-    auto set_src = [&](int64_t tm) {
+    auto set_src = [&](int item) {
+        const int64_t tm = (int64_t)(item / tiles_f) * 8 + xcd;
+        const int tf = item % tiles_f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int row = (wave + 8 * i) * 8 + lrow;
             const int lch = pch ^ ((row >> 1) & 7);
-            int64_t m = tm * BM + row;
-            if (m >= a.M) m = a.M - 1;                               // clamp: such rows are never stored
-            asrc[i] = Ag + m * a.lda + lch * EPC;
+            if (i < MT) {
+                int64_t m = tm * BM + row;
+                if (m >= a.M) m = a.M - 1;                           // clamp: such rows are never stored
+                asrc[i] = Ag + m * a.lda + lch * EPC;
+            }
+            wsrc[i] = Wg + (int64_t)(tf * BN + row) * a.K + lch * EPC;
         }
     };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave + 8 * i) * 8 + lrow;
-        const int lch = pch ^ ((row >> 1) & 7);
-        wsrc[i] = Wg + (int64_t)(f0 + row) * a.K + lch * EPC;
-    }
-    set_src(tile_m);
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto stage = [&](int buf, int kt) {
@@ -312,26 +325,44 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     };
 
     const int nk = a.K / BK;
-    if (EPI == EPI_FWD && tid < BN) bias_s[tid] = a.bias[f0 + tid];
-    if (EPI == EPI_DGRAD_BN) {
-        for (int q = tid; q < 3 * BN; q += 512) bias_s[q] = a.coef[(q / BN) * a.coef_mod + (f0 + q % BN) % a.coef_mod];
-    }
+    if (tid == 0) s_item[0] = atomicAdd(ctr, 1);
+    if constexpr (EPI == EPI_FWD)
+        for (int q = tid; q < a.F; q += 512) bias_all[q] = a.bias[q];
+    if constexpr (EPI == EPI_DGRAD_BN)
+        for (int q = tid; q < tiles_f * 3 * BN; q += 512) {
+            const int tf = q / (3 * BN), c = (q / BN) % 3, f = tf * BN + q % BN;
+            bias_all[q] = a.coef[c * a.coef_mod + f % a.coef_mod];
+        }
     const uint32_t dkey = (EPI == EPI_DGRAD_ST && a.dp_thresh != 0) ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
-    // column sums carried across the block's tiles: ONE value per lane and statistic (the tile's 32-lane reduction is
-    // finished every tile: 7 extra shuffles per statistic, and 14 registers fewer through the K loop than carrying the
-    // half-reduced sums).  Lane r of half h holds value r = i*16 + 4q + e.
-    float tot1 = 0.f, tot2 = 0.f;
+    // the block's second item is drawn only now, behind every other block's first: neighbouring items -- the column
+    // tiles of one sample tile -- go to different CUs at the same time and share the tile's rows in L2
+    int cur = __builtin_amdgcn_readfirstlane(s_item[0]);   // block-uniform: keep the tile bookkeeping in SGPRs
+    int slot = 0;                                        // s_item[slot] takes the pull issued at the start of the current tile
     T* Cg = (T*)a.C;
     int buf = 0;
+    if (cur < items) {
+        int pulled = 0;
+        if (tid == 0) pulled = atomicAdd(ctr, 1);
+        set_src(cur);
+        stage(0, 0);
+        if (tid == 0) s_item[1] = pulled;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int nxt = cur < items ? __builtin_amdgcn_readfirstlane(s_item[1]) : 0;
 
-    while (true) {
-        const int64_t m0 = tile_m * BM;
-        const int64_t next_m = tile_m + stride_m;
-        const bool has_next = next_m < tiles_m;
+    while (cur < items) {
+        const int64_t m0 = ((int64_t)(cur / tiles_f) * 8 + xcd) * BM;
+        const int tf = cur % tiles_f;
+        const int f0 = tf * BN;
+        const bool has_next = nxt < items;
+        // the item after the next one: requested a whole tile ahead, parked in LDS behind the first K step (whose closing
+        // wait and barrier it shares: waiting for the counter's round trip here cost 10 us per launch), read at the end
+        // of this tile; the slots alternate so the next tile's pull cannot overtake that read
+        int pulled = 0;
+        if (tid == 0 && has_next) pulled = atomicAdd(ctr, 1);
+        const float* bias_s = bias_all + tf * (EPI == EPI_DGRAD_BN ? 3 * BN : BN);
         f32x16 acc[2][MT];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -363,25 +394,26 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             // reads: +1 % step time; behind the first MFMA group: +3 %)
             asm volatile("" ::: "memory");
             if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-            else if (has_next) { set_src(next_m); stage(buf ^ 1, 0); }
+            else if (has_next) { set_src(nxt); stage(buf ^ 1, 0); }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int cur = ks & 1, nxt = cur ^ 1;
+                const int cur_f = ks & 1, nxt_f = cur_f ^ 1;
                 if (ks + 1 < 4) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        fw[nxt][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, 2 * (ks + 1) + h));
+                        fw[nxt_f][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, 2 * (ks + 1) + h));
 #pragma unroll
                     for (int jj = 0; jj < MT; ++jj)
-                        fs[nxt][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, 2 * (ks + 1) + h));
+                        fs[nxt_f][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, 2 * (ks + 1) + h));
                 }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < MT; ++jj) mma_chunk<T>(fw[cur][i], fs[cur][jj], acc[i][jj]);
+                    for (int jj = 0; jj < MT; ++jj) mma_chunk<T>(fw[cur_f][i], fs[cur_f][jj], acc[i][jj]);
                 __builtin_amdgcn_s_setprio(0);
             }
+            if (kt == 0 && tid == 0 && has_next) s_item[slot] = pulled;
             // the stage requested above has had this step's MFMAs to land; every wave is done reading buf
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -395,7 +427,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             // four quarters (sample tiles jj = 0..3); two 32 KiB halves of the released ring buffer take them in
             // turn.  Waits are counted: vmcnt retires in issue order, so "all but the N youngest" leaves a quarter's 4 stores
             // and the NEXT quarter's 4 DMAs in flight while guaranteeing the quarter about to be read has landed (a ragged
-            // tile, whose row-masked stores may be skipped, waits for everything instead; it is always a block's last tile).
+            // tile, whose row-masked stores may be skipped, waits for everything instead).
             // One instantiation with row masks serves both: a second, mask-free copy of this code cost registers.
             // The epilogue's per-lane index arithmetic (16 DMA sources, LDS offsets, store addresses) is tile-invariant;
             // hoisted out of the tile loop it would sit in ~60 registers through the K loop and spill.  An opaque zero,
@@ -435,7 +467,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             if (m0 + BM > a.M) nt256p_convert<EPI, MT, false>(a, acc, mw0, base, r, lane, qs1, qs2);
             else nt256p_convert<EPI, MT, true>(a, acc, mw0, base, r, lane, qs1, qs2);
         }
-        if constexpr (EPI == EPI_FWD || RMODE) {
+        if constexpr (STATS) {
             // remaining butterfly steps (lane bits 2..4)
 #pragma unroll
             for (int s = 2, n = 8; s < 5; ++s, n >>= 1) {
@@ -450,39 +482,69 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
                     }
                 }
             }
-            tot1 += qs1[0];
-            tot2 += qs2[0];
+            // lane r of half h holds value r = i*16 + 4q + e  ->  feature wf*64 + i*32 + 8q + 4h + e.  One partial row
+            // per sample tile, whichever block ran it: the sums downstream do not depend on the schedule.
+            const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
+            red[ws * BN + fl] = qs1[0];
+            if constexpr (EPI != EPI_DGRAD_BN) red[(2 + ws) * BN + fl] = qs2[0];
+            __syncthreads();                                   // the next write of red is a K loop of barriers away
+            const int which = tid / BN, col = tid % BN;
+            const int64_t prow = (int64_t)(cur / tiles_f) * 8 + xcd;
+            const float v = red[(which * 2) * BN + col] + red[(which * 2 + 1) * BN + col];
+            if constexpr (EPI == EPI_DGRAD_BN) {
+                if (which == 0) a.partials[prow * a.F + f0 + col] = v;            // bias gradient of the layer below: rows of F
+            } else {
+                a.partials[(prow * 2 + which) * a.F + f0 + col] = v;
+            }
         }
         if (!has_next) break;
-        tile_m = next_m;
+        cur = nxt;
+        nxt = __builtin_amdgcn_readfirstlane(s_item[slot]);
+        slot ^= 1;
     }
 
-    if constexpr (EPI == EPI_FWD || RMODE) {
-        // lane r of half h holds value r = i*16 + 4q + e  ->  feature wf*64 + i*32 + 8q + 4h + e
-        const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
-        red[(0 * 2 + ws) * BN + fl] = tot1;
-        red[(1 * 2 + ws) * BN + fl] = tot2;
-        __syncthreads();
-        const int which = tid / BN, col = tid % BN;
-        const int64_t prow = (int64_t)jm * 8 + xcd;
-        const float v = red[(which * 2 + 0) * BN + col] + red[(which * 2 + 1) * BN + col];
-        if constexpr (EPI == EPI_DGRAD_BN) {
-            if (which == 0) a.partials[prow * a.F + f0 + col] = v;          // bias gradient of the layer below: rows of F
-        } else {
-            a.partials[(prow * 2 + which) * a.F + f0 + col] = v;
+    // the last block out leaves the counters at zero for the next launch on this stream
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(a.sched + 8 * 32, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x < 9; ++x) a.sched[x * 32] = 0;
+            __threadfence();
         }
     }
 }
 
-// One block per CU in whole XCD rows.  *stat_rows = partial rows written (EPI_FWD).  EPI_FWD always applies
-// ReLU (every fc layer of the reference has one; the projection runs the 128-tile kernel).
+// One block per CU; the blocks of an XCD draw its tiles from a counter, so a CU that starts late or is shared with
+// another stream's kernel (RCCL's, at N > 1) takes fewer tiles instead of holding the launch back: beside 8-32 held
+// CUs the statically assigned version of this kernel ran 202-208 us instead of 150 (tools/contention_bench.py).
+// The counters live in a per-stream slot of a module-global table, zero at load and re-zeroed by the last block of
+// every launch.  *stat_rows = partial rows written.  EPI_FWD always applies ReLU (every fc layer of the reference
+// has one; the projection runs the 128-tile kernel).
+__device__ int g_nt256p_sched[NT256P_SCHED_SLOTS][9 * 32];      // [8 XCD counters + blocks finished] x 128 bytes
+
+static inline int* nt256p_sched_slot(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t seen[NT256P_SCHED_SLOTS];
+    static int n = 0;
+    static int* table = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!table && hipGetSymbolAddress((void**)&table, HIP_SYMBOL(g_nt256p_sched)) != hipSuccess) return nullptr;
+    int s = 0;
+    while (s < n && seen[s] != st) ++s;
+    if (s == n) {
+        if (n == NT256P_SCHED_SLOTS) return nullptr;
+        seen[n++] = st;
+    }
+    return table + s * 9 * 32;
+}
+
 template <int EPI>
-static inline hipError_t launch_gemm_nt256p(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
-    const int tiles_f = a.F / 256;
-    const int J = 32 - (32 % tiles_f);                       // blocks per XCD, a multiple of tiles_f
-    const int64_t slots = (int64_t)(J / tiles_f) * 8;        // sample tiles per round
-    const int64_t tiles_m = (a.M + 255) / 256;
-    if (stat_rows) *stat_rows = (int)(tiles_m < slots ? tiles_m : slots);
-    hipLaunchKernelGGL((gemm_nt256p_kernel<EPI, 4>), dim3(8 * J), dim3(512), 0, st, a);
+static inline hipError_t launch_gemm_nt256p(GemmNTArgs a, hipStream_t st, int* stat_rows) {
+    if (a.F / 256 > NT256P_MAX_TILES_F) return hipErrorInvalidValue;
+    a.sched = nt256p_sched_slot(st);
+    if (!a.sched) return hipErrorOutOfMemory;
+    const int blocks = 256;
+    if (stat_rows) *stat_rows = (int)((a.M + 255) / 256);     // one partial row per sample tile
+    hipLaunchKernelGGL((gemm_nt256p_kernel<EPI, 4>), dim3(blocks), dim3(512), 0, st, a);
     return hipGetLastError();
 }

@@ -37,36 +37,60 @@ __global__ void gather_groups_kernel(const float* __restrict__ table, const int6
 // partials: [nrows][2][C] (sum, sum of squares).  use_running: eval with stock BN.
 // stats out: [4][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
 // ------------------------------------------------------------------------------------
-// (finalize kernels: 64 columns x blockDim.x/64 row lanes per block, launched with FIN_THREADS = 1024 so that up to
-//  FIN_DIRECT_ROWS partial rows are folded here directly -- 48 rows per lane -- without a reduce_rows_kernel launch first)
+// (finalize kernels: FIN_COLS columns x FIN_LANES row lanes per block of FIN_THREADS, FIN_GRID(C) blocks: up to
+//  FIN_DIRECT_ROWS partial rows -- 12 per lane -- are folded here directly, without a reduce_rows_kernel launch first.
+//  With 64 columns x 16 row lanes the 512-column layers ran on 8 blocks and 656 rows took 9-16 us.)
 #define FIN_THREADS 1024
-#define FIN_LANES (FIN_THREADS / 64)
+#define FIN_COLS 16
+#define FIN_LANES (FIN_THREADS / FIN_COLS)
+#define FIN_GRID(C) (((C) + FIN_COLS - 1) / FIN_COLS)
 #define FIN_DIRECT_ROWS 768
+// sum over the block's row lanes of one value per thread (thread = column cl + FIN_COLS * row lane): the four row
+// lanes of a wave by shuffles, the 16 waves through red; valid in the threads tid < FIN_COLS
+__device__ __forceinline__ double fin_block_sum(double s, double (*red)[FIN_COLS], int tid) {
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if ((tid & 63) < FIN_COLS) red[tid >> 6][tid & 63] = s;
+    __syncthreads();
+    double t = 0;
+    if (tid < FIN_COLS)
+        for (int q = 0; q < FIN_THREADS / 64; ++q) t += red[q][tid];
+    return t;
+}
+// s += p[r * stride] for r = g, g + L, ... < nrows, in that order; the loads go out eight rows at a time (one row per
+// round trip made 656 rows cost 16 us instead of 6)
+__device__ __forceinline__ void fin_fold_rows(const float* __restrict__ p, int nrows, int g, int L, int64_t stride, double& s) {
+    int r = g;
+    for (; r + 7 * L < nrows; r += 8 * L) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(r + u * L) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; r < nrows; r += L) s += (double)p[(int64_t)r * stride];
+}
 __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* __restrict__ partials, int nrows, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, int update_running,
                                                           int use_running, float momentum, float eps,
                                                           float* __restrict__ stats, int C) {
-    __shared__ double red[2][FIN_LANES][64];
-    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6, L = blockDim.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[2][FIN_THREADS / 64][FIN_COLS];
+    const int tid = threadIdx.x, cl = tid % FIN_COLS, g = tid / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cl;
     double s1 = 0, s2 = 0;
-    if (!use_running)
-        for (int r = g; r < nrows; r += L) {
-            s1 += (double)partials[((int64_t)r * 2 + 0) * C + c];
-            s2 += (double)partials[((int64_t)r * 2 + 1) * C + c];
-        }
-    red[0][g][cl] = s1;
-    red[1][g][cl] = s2;
-    __syncthreads();
-    if (g == 0) {
+    if (!use_running && c < C) {
+        fin_fold_rows(partials + c, nrows, g, FIN_LANES, 2 * (int64_t)C, s1);
+        fin_fold_rows(partials + C + c, nrows, g, FIN_LANES, 2 * (int64_t)C, s2);
+    }
+    s1 = fin_block_sum(s1, red[0], tid);
+    s2 = fin_block_sum(s2, red[1], tid);
+    if (g == 0 && c < C) {
         float mean, var;
         if (use_running) {
             mean = running_mean[c];
             var = running_var[c];
         } else {
-            s1 = s2 = 0;
-            for (int q = 0; q < L; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
             const double mu = s1 / count;
             double vb = s2 / count - mu * mu;
             if (vb < 0) vb = 0;
@@ -206,22 +230,26 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const floa
                                                               int nfold) {
     // nfold > 1: the partial rows are nfold*C wide (feature = w*C + channel, conv stack seen
     // through the first Linear); the BatchNorm2d channel statistic sums over w.
-    __shared__ double red[2][FIN_LANES][64];
-    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6, L = blockDim.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[2][FIN_THREADS / 64][FIN_COLS];
+    const int tid = threadIdx.x, cl = tid % FIN_COLS, g = tid / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cl;
     const int W = C * nfold;
     double s1 = 0, s2 = 0;
-    for (int r = g; r < nrows; r += L)
-        for (int f = 0; f < nfold; ++f) {
-            s1 += (double)partials[((int64_t)r * 2 + 0) * W + f * C + c];
-            s2 += (double)partials[((int64_t)r * 2 + 1) * W + f * C + c];
+    if (c < C) {
+        if (nfold == 1) {
+            fin_fold_rows(partials + c, nrows, g, FIN_LANES, 2 * (int64_t)W, s1);
+            fin_fold_rows(partials + W + c, nrows, g, FIN_LANES, 2 * (int64_t)W, s2);
+        } else {
+            for (int r = g; r < nrows; r += FIN_LANES)
+                for (int f = 0; f < nfold; ++f) {
+                    s1 += (double)partials[((int64_t)r * 2 + 0) * W + f * C + c];
+                    s2 += (double)partials[((int64_t)r * 2 + 1) * W + f * C + c];
+                }
         }
-    red[0][g][cl] = s1;
-    red[1][g][cl] = s2;
-    __syncthreads();
-    if (g == 0) {
-        s1 = s2 = 0;
-        for (int q = 0; q < L; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
+    }
+    s1 = fin_block_sum(s1, red[0], tid);
+    s2 = fin_block_sum(s2, red[1], tid);
+    if (g == 0 && c < C) {
         const double mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c];
         const double dot = (s2 - mean * s1) * invstd;          // sum g * x_hat
         const double c1 = s1 / count, c2 = dot / count;
@@ -319,22 +347,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 }
 
 // out[c] = sum_rows partials[row][c]  (f64 accumulation; one thread per column)
-// grid ceil(C/64) blocks of FIN_THREADS (64 columns x row lanes)
+// grid FIN_GRID(C) blocks of FIN_THREADS
 __global__ __launch_bounds__(FIN_THREADS) void colsum_finalize_kernel(const float* __restrict__ partials, int nrows, int C,
                                                                       float* __restrict__ out) {
-    __shared__ double red[FIN_LANES][64];
-    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6, L = blockDim.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[FIN_THREADS / 64][FIN_COLS];
+    const int tid = threadIdx.x, cl = tid % FIN_COLS, g = tid / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cl;
     double s = 0;
-    if (c < C)
-        for (int r = g; r < nrows; r += L) s += (double)partials[(int64_t)r * C + c];
-    red[g][cl] = s;
-    __syncthreads();
-    if (g == 0 && c < C) {
-        s = 0;
-        for (int q = 0; q < L; ++q) s += red[q][cl];
-        out[c] = (float)s;
-    }
+    if (c < C) fin_fold_rows(partials + c, nrows, g, FIN_LANES, C, s);
+    s = fin_block_sum(s, red, tid);
+    if (g == 0 && c < C) out[c] = (float)s;
 }
 
 // dW1[c][0][1][tap] and db1[c] from the partials; the other kernel rows get zero data gradient.

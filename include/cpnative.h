@@ -253,6 +253,9 @@ int cp_debug_activation(const cp_config* cfg, const cp_params* p, const float* x
  * kind 1: data grad C[M][F] = A[M][K] W[F][K]^T, sums against R[M][F] -> partials
  * kind 2: weight grad slabs[S][P][Q] = sum_m X[m][P] Y[m][Q]   (A = X, W = Y, K = P, F = Q)
  * dbg: ablation bits of the bf16 kernels (1 skip MFMA, 2 skip epilogue, 4 skip staging loads). */
+/* test aid: `blocks` workgroups of 256 threads that each hold a CU's LDS (so nothing else fits next to them there) and spin
+ * for about `microseconds` -- stands in for another stream's kernel (an RCCL collective) competing for CUs. */
+int cp_debug_hog(int32_t blocks, int32_t microseconds, void* stream);
 int cp_debug_gemm(int32_t dtype, int32_t kind, int64_t M, int32_t K, int32_t F, const void* A,
                   const void* W, void* C, const float* bias, const void* R, float* partials,
                   int32_t dbg, void* stream);
