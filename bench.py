@@ -143,6 +143,9 @@ def main():
             dist.init_process_group(rehearse)
         else:
             dist.init_process_group("nccl", device_id=dev)
+        # the collectives' kernels hold CUs while backward GEMMs run: dynamic tile schedule (include/cpnative.h)
+        from contrastiveprosthetics_amd.dist import share_gpu_with_other_kernels
+        share_gpu_with_other_kernels()
 
     from contrastiveprosthetics_amd.engine import Engine
 
@@ -272,7 +275,8 @@ def main():
                                         f"({N} windows/GPU/step), {'AdaBN' if args.adabn else 'stock BN (--no_adabn)'}, "
                                         f"dp_emg={args.dp_emg}, d_e=16, random-init weights",
                                global_batch_groups=world * B, windows_per_step=world * N,
-                               parallelism=f"dp{world}" + (" + z all-gather + flat-gradient all-reduce (RCCL)" if world > 1 else "")),
+                               parallelism=f"dp{world}" + (" + z all-gather + flat-gradient all-reduce (RCCL)" if world > 1 else ""),
+                               tile_schedule="dynamic" if eng.lib.cp_get_tile_schedule() else "static"),
                    loss=loss, train_acc=correct / N, roofline=roof)
         if rehearse:
             rec["rehearsal"] = f"ranks share one GPU over {rehearse}: control-flow check only, not a measurement"

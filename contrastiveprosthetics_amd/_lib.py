@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpnative.so")
+# CPNATIVE_LIB: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("CPNATIVE_LIB") or os.path.join(_HERE, "libcpnative.so")
 
 CP_F32, CP_BF16 = 0, 1
 CP_TASKS, CP_EMG_DIM, CP_D_E, CP_N_BN, CP_N_FC = 41, 12, 16, 9, 7
@@ -81,6 +82,8 @@ SYMBOLS = {
     "cp_l2_adam_step_graph": (C.c_int, [_fp, _fp, _fp, _fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32),
                                         C.c_int32, _P(cp_adam_hyper), _fp, _fp, _fp, _fp]),
     "cp_debug_hog": (C.c_int, [C.c_int32, C.c_int32, _fp]),
+    "cp_set_tile_schedule": (C.c_int, [C.c_int32]),
+    "cp_get_tile_schedule": (C.c_int, []),
     "cp_profile_enable": (C.c_int, [C.c_uint64, C.c_int32]),
     "cp_profile_disable": (C.c_int, []),
     "cp_profile_summary": (C.c_int, [C.c_int32, _P(C.c_double), _P(C.c_int64)]),

@@ -41,6 +41,22 @@ static int fail(int code, const char* what) {
 extern "C" int cp_version(void) { return CP_VERSION; }
 extern "C" const char* cp_last_error(void) { return g_err; }
 
+// tile schedule of the persistent fc GEMM kernels (cpnative.h); -1 = not chosen yet: $CPNATIVE_TILE_SCHEDULE or static
+static int g_tile_schedule = -1;
+static int tile_schedule() {
+    if (g_tile_schedule < 0) {
+        const char* e = getenv("CPNATIVE_TILE_SCHEDULE");
+        g_tile_schedule = (e && !strcmp(e, "dynamic")) ? CP_TILES_DYNAMIC : CP_TILES_STATIC;
+    }
+    return g_tile_schedule;
+}
+extern "C" int cp_set_tile_schedule(int32_t mode) {
+    if (mode != CP_TILES_STATIC && mode != CP_TILES_DYNAMIC) return fail(CP_ERR_ARG, "cp_set_tile_schedule: mode");
+    g_tile_schedule = mode;
+    return 0;
+}
+extern "C" int cp_get_tile_schedule(void) { return tile_schedule(); }
+
 // ---------------------------------------------------------------------------------------
 // optional per-kernel-kind timing with HIP events recorded on the launch stream
 // (bench.py's live roofline measurement).  Events are created in cp_profile_enable, never
@@ -242,10 +258,12 @@ template <typename T, int EPI>
 static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int* stat_rows = nullptr) {
     if (stat_rows) *stat_rows = (int)((a.M + fc_bm<T>() - 1) / fc_bm<T>());
     if constexpr (sizeof(T) == 2) {
-        if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows);
+        // (dbg 64 / 128, tools only: force the dynamic / static schedule for this launch)
+        const bool dyn = (a.dbg & 64) ? true : (a.dbg & 128) ? false : tile_schedule() == CP_TILES_DYNAMIC;
+        if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows, dyn);
         if (EPI == EPI_DGRAD && a.R != nullptr && !(a.dbg & 16) && !getenv("CPNATIVE_STAGED_R_EPILOGUE")) {
             // the persistent kernel's R epilogues: BN + ReLU backward of the layer below (coef), or dropout + BN-backward sums
-            return a.coef ? launch_gemm_nt256p<EPI_DGRAD_BN>(a, st, stat_rows) : launch_gemm_nt256p<EPI_DGRAD_ST>(a, st, stat_rows);
+            return a.coef ? launch_gemm_nt256p<EPI_DGRAD_BN>(a, st, stat_rows, dyn) : launch_gemm_nt256p<EPI_DGRAD_ST>(a, st, stat_rows, dyn);
         }
         return launch_gemm_nt256<EPI>(a, st);
     } else {

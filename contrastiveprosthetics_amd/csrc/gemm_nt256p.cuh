@@ -10,18 +10,21 @@
 // from the accumulator registers, no LDS staging, no barrier (see the register-direct epilogue in
 // gemm_nt256.cuh) -- drain underneath tile n+1's first K step.
 //
-// Tile schedule (XCD-aware, dynamic): block b runs on XCD b & 7 and draws that XCD's tiles -- sample tile
+// Tile schedule, XCD-aware, two forms behind one template flag (cp_set_tile_schedule picks per process).
+// Dynamic: block b runs on XCD b & 7 and draws that XCD's tiles -- sample tile
 // (item / tiles_f) * 8 + xcd, column tile item % tiles_f -- from a per-XCD counter, one tile ahead of the one it
 // is computing.  Neighbouring items share an A tile and are drawn by different blocks at about the same time, so
 // its second read is an L2 hit.  The bias / BatchNorm coefficients of every column tile sit in LDS; the
 // BatchNorm column sums leave as ONE partial row per SAMPLE TILE (not per block), so the sums downstream add
 // up in the same order whichever block ran which tile: results do not depend on the schedule.
-// The first version of this kernel assigned tiles statically (block j of an XCD: fixed column tile, every
-// (J/tiles_f)-th sample tile, sums carried in registers, one partial row per block).  Alone on the GPU that ran
-// 2-4 % faster (145 / 180 / 170 us for the three fc launches against 148 / 185 / 176), but with 8-32 CUs held by
-// another stream's kernel -- RCCL at N > 1, a neighbour process in a packed hyper-parameter sweep -- the blocks
-// that start late hold the whole launch back: 202-208 us against 150, where this version stays at 150
-// (tools/contention_bench.py).
+// Static: block j of an XCD has a fixed column tile and every (J/tiles_f)-th sample tile, carries the sums in
+// registers and writes one partial row per block.  Alone on the GPU that is 2-3 % faster (147 / 182 / 174 us for the
+// three fc launches against 150 / 187 / 178, tools/ab_sched.sh), but with 8-32 CUs held by another stream's kernel
+// -- RCCL at N > 1, a neighbour process in a packed hyper-parameter sweep -- the blocks that start late hold the
+// whole launch back: 201-210 us against 150, where the dynamic form stays at 148-149 (tools/contention_bench.py).
+// Measured on the dynamic form and dropped: flushing a tile's sums from the first K step of the next tile instead
+// of behind a barrier of their own (+5 us forward: the K loop does not tolerate extra code), drawing two tiles ahead
+// with an untracked asm atomic plus per-half partial rows written straight from registers (+4 us forward).
 // Also measured on top of the dynamic schedule: handing out the leftover round (164 tiles on an XCD's 32 CUs = 5
 // rounds + 4 tiles) in quarter tiles of 64 rows.  A quarter's K step has 8 MFMAs per wave to cover the same
 // stage latency, so it took well over half a tile's time: forward 154 us instead of 148.
@@ -261,7 +264,10 @@ __device__ __forceinline__ void nt256p_quarter(const GemmNTArgs& a, f32x16 (&acc
 // weight-tile refills cost what the rounding saved; holding a converted 192-row tile in 48 registers to
 // release its stores two per K step of the next tile made hipcc spill (118-280 VGPRs) and ran 1.4-1.8x
 // slower.  The launcher therefore uses MT = 4.
-template <int EPI, int MT>
+// DYN: tiles drawn from the per-XCD counters (above); !DYN: the static assignment, block j of an XCD takes items
+// j, j + J, j + 2J, ... (J = blocks per XCD, a multiple of tiles_f, so its column tile is fixed), carries the column
+// sums in registers across its tiles and writes one partial row.
+template <int EPI, int MT, bool DYN>
 __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     using T = bf16_t;
     constexpr int BM = 64 * MT, BN = 256, BK = 64, EPC = 8;
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     // item % tiles_f, so the column tiles of one sample tile run at about the same time behind the same L2
     const int items = xcd < tiles_m ? (int)((tiles_m - xcd + 7) / 8) * tiles_f : 0;
     int* ctr = a.sched + xcd * 32;                       // a 128-byte line per counter
+    const int J = gridDim.x >> 3;
     const int ws = wave >> 2, wf = wave & 3;
 
     const T* __restrict__ Ag = (const T*)a.A;
@@ -295,21 +302,28 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     const int lrow = lane >> 3, pch = lane & 7;
     const T* asrc[MT];
     const T* wsrc[4];
-    auto set_src = [&](int item) {
-        const int64_t tm = (int64_t)(item / tiles_f) * 8 + xcd;
-        const int tf = item % tiles_f;
+    const int tf_static = (int)(blockIdx.x >> 3) % tiles_f;     // !DYN: the block's column tile
+    auto set_wsrc = [&](int tf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (wave + 8 * i) * 8 + lrow;
             const int lch = pch ^ ((row >> 1) & 7);
-            if (i < MT) {
-                int64_t m = tm * BM + row;
-                if (m >= a.M) m = a.M - 1;                           // clamp: such rows are never stored
-                asrc[i] = Ag + m * a.lda + lch * EPC;
-            }
             wsrc[i] = Wg + (int64_t)(tf * BN + row) * a.K + lch * EPC;
         }
     };
+    auto set_src = [&](int item) {
+        const int64_t tm = (int64_t)(item / tiles_f) * 8 + xcd;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = (wave + 8 * i) * 8 + lrow;
+            const int lch = pch ^ ((row >> 1) & 7);
+            int64_t m = tm * BM + row;
+            if (m >= a.M) m = a.M - 1;                               // clamp: such rows are never stored
+            asrc[i] = Ag + m * a.lda + lch * EPC;
+        }
+        if constexpr (DYN) set_wsrc(item % tiles_f);
+    };
+    if constexpr (!DYN) set_wsrc(tf_static);
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto stage = [&](int buf, int kt) {
@@ -325,7 +339,8 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     };
 
     const int nk = a.K / BK;
-    if (tid == 0) s_item[0] = atomicAdd(ctr, 1);
+    if constexpr (DYN)
+        if (tid == 0) s_item[0] = atomicAdd(ctr, 1);
     if constexpr (EPI == EPI_FWD)
         for (int q = tid; q < a.F; q += 512) bias_all[q] = a.bias[q];
     if constexpr (EPI == EPI_DGRAD_BN)
@@ -337,31 +352,35 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     __syncthreads();
     // the block's second item is drawn only now, behind every other block's first: neighbouring items -- the column
     // tiles of one sample tile -- go to different CUs at the same time and share the tile's rows in L2
-    int cur = __builtin_amdgcn_readfirstlane(s_item[0]);   // block-uniform: keep the tile bookkeeping in SGPRs
+    int cur = DYN ? __builtin_amdgcn_readfirstlane(s_item[0]) : (int)(blockIdx.x >> 3);   // block-uniform: SGPRs
     int slot = 0;                                        // s_item[slot] takes the pull issued at the start of the current tile
     T* Cg = (T*)a.C;
     int buf = 0;
     if (cur < items) {
         int pulled = 0;
-        if (tid == 0) pulled = atomicAdd(ctr, 1);
+        if constexpr (DYN)
+            if (tid == 0) pulled = atomicAdd(ctr, 1);
         set_src(cur);
         stage(0, 0);
-        if (tid == 0) s_item[1] = pulled;
+        if constexpr (DYN)
+            if (tid == 0) s_item[1] = pulled;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    int nxt = cur < items ? __builtin_amdgcn_readfirstlane(s_item[1]) : 0;
+    int nxt = !DYN ? cur + J : cur < items ? __builtin_amdgcn_readfirstlane(s_item[1]) : 0;
+    float tot1 = 0.f, tot2 = 0.f;                        // !DYN: column sums over the block's tiles (see the reduction below)
 
     while (cur < items) {
         const int64_t m0 = ((int64_t)(cur / tiles_f) * 8 + xcd) * BM;
-        const int tf = cur % tiles_f;
+        const int tf = DYN ? cur % tiles_f : tf_static;
         const int f0 = tf * BN;
         const bool has_next = nxt < items;
         // the item after the next one: requested a whole tile ahead, parked in LDS behind the first K step (whose closing
         // wait and barrier it shares: waiting for the counter's round trip here cost 10 us per launch), read at the end
         // of this tile; the slots alternate so the next tile's pull cannot overtake that read
         int pulled = 0;
-        if (tid == 0 && has_next) pulled = atomicAdd(ctr, 1);
+        if constexpr (DYN)
+            if (tid == 0 && has_next) pulled = atomicAdd(ctr, 1);
         const float* bias_s = bias_all + tf * (EPI == EPI_DGRAD_BN ? 3 * BN : BN);
         f32x16 acc[2][MT];
 #pragma unroll
@@ -413,7 +432,8 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
                     for (int jj = 0; jj < MT; ++jj) mma_chunk<T>(fw[cur_f][i], fs[cur_f][jj], acc[i][jj]);
                 __builtin_amdgcn_s_setprio(0);
             }
-            if (kt == 0 && tid == 0 && has_next) s_item[slot] = pulled;
+            if constexpr (DYN)
+                if (kt == 0 && tid == 0 && has_next) s_item[slot] = pulled;
             // the stage requested above has had this step's MFMAs to land; every wave is done reading buf
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -484,26 +504,55 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             }
             // lane r of half h holds value r = i*16 + 4q + e  ->  feature wf*64 + i*32 + 8q + 4h + e.  One partial row
             // per sample tile, whichever block ran it: the sums downstream do not depend on the schedule.
-            const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
-            red[ws * BN + fl] = qs1[0];
-            if constexpr (EPI != EPI_DGRAD_BN) red[(2 + ws) * BN + fl] = qs2[0];
-            __syncthreads();                                   // the next write of red is a K loop of barriers away
-            const int which = tid / BN, col = tid % BN;
-            const int64_t prow = (int64_t)(cur / tiles_f) * 8 + xcd;
-            const float v = red[(which * 2) * BN + col] + red[(which * 2 + 1) * BN + col];
-            if constexpr (EPI == EPI_DGRAD_BN) {
-                if (which == 0) a.partials[prow * a.F + f0 + col] = v;            // bias gradient of the layer below: rows of F
+            if constexpr (DYN) {
+                const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
+                red[ws * BN + fl] = qs1[0];
+                if constexpr (EPI != EPI_DGRAD_BN) red[(2 + ws) * BN + fl] = qs2[0];
+                __syncthreads();                               // the next write of red is a K loop of barriers away
+                const int which = tid / BN, col = tid % BN;
+                const int64_t prow = (int64_t)(cur / tiles_f) * 8 + xcd;
+                const float v = red[(which * 2) * BN + col] + red[(which * 2 + 1) * BN + col];
+                if constexpr (EPI == EPI_DGRAD_BN) {
+                    if (which == 0) a.partials[prow * a.F + f0 + col] = v;        // bias gradient of the layer below: rows of F
+                } else {
+                    a.partials[(prow * 2 + which) * a.F + f0 + col] = v;
+                }
             } else {
-                a.partials[(prow * 2 + which) * a.F + f0 + col] = v;
+                tot1 += qs1[0];
+                tot2 += qs2[0];
             }
         }
         if (!has_next) break;
         cur = nxt;
-        nxt = __builtin_amdgcn_readfirstlane(s_item[slot]);
-        slot ^= 1;
+        if constexpr (DYN) {
+            nxt = __builtin_amdgcn_readfirstlane(s_item[slot]);
+            slot ^= 1;
+        } else {
+            nxt += J;
+        }
     }
 
+    if constexpr (STATS && !DYN) {
+        // one partial row per block and column tile: row (j / tiles_f) * 8 + xcd, the block's first sample tile
+        const int j = blockIdx.x >> 3;
+        if (j < items) {
+            const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
+            red[ws * BN + fl] = tot1;
+            red[(2 + ws) * BN + fl] = tot2;
+            __syncthreads();
+            const int which = tid / BN, col = tid % BN;
+            const int64_t prow = (int64_t)(j / tiles_f) * 8 + xcd;
+            const int f0 = (j % tiles_f) * BN;
+            const float v = red[(which * 2) * BN + col] + red[(which * 2 + 1) * BN + col];
+            if constexpr (EPI == EPI_DGRAD_BN) {
+                if (which == 0) a.partials[prow * a.F + f0 + col] = v;
+            } else {
+                a.partials[(prow * 2 + which) * a.F + f0 + col] = v;
+            }
+        }
+    }
     // the last block out leaves the counters at zero for the next launch on this stream
+    if constexpr (DYN)
     if (tid == 0) {
         __threadfence();
         if (atomicAdd(a.sched + 8 * 32, 1) == (int)gridDim.x - 1) {
@@ -538,13 +587,24 @@ static inline int* nt256p_sched_slot(hipStream_t st) {
     return table + s * 9 * 32;
 }
 
+// dynamic: tiles drawn from the per-XCD counters (a GPU shared with other streams or processes); otherwise the static
+// assignment (2-4 % faster alone on the GPU)
 template <int EPI>
-static inline hipError_t launch_gemm_nt256p(GemmNTArgs a, hipStream_t st, int* stat_rows) {
-    if (a.F / 256 > NT256P_MAX_TILES_F) return hipErrorInvalidValue;
-    a.sched = nt256p_sched_slot(st);
-    if (!a.sched) return hipErrorOutOfMemory;
-    const int blocks = 256;
-    if (stat_rows) *stat_rows = (int)((a.M + 255) / 256);     // one partial row per sample tile
-    hipLaunchKernelGGL((gemm_nt256p_kernel<EPI, 4>), dim3(blocks), dim3(512), 0, st, a);
+static inline hipError_t launch_gemm_nt256p(GemmNTArgs a, hipStream_t st, int* stat_rows, bool dynamic) {
+    const int tiles_f = a.F / 256;
+    if (tiles_f > NT256P_MAX_TILES_F) return hipErrorInvalidValue;
+    const int64_t tiles_m = (a.M + 255) / 256;
+    if (dynamic) {
+        a.sched = nt256p_sched_slot(st);
+        if (!a.sched) return hipErrorOutOfMemory;
+        if (stat_rows) *stat_rows = (int)tiles_m;                // one partial row per sample tile
+        hipLaunchKernelGGL((gemm_nt256p_kernel<EPI, 4, true>), dim3(256), dim3(512), 0, st, a);
+    } else {
+        const int J = 32 - (32 % tiles_f);                       // blocks per XCD, a multiple of tiles_f
+        const int64_t slots = (int64_t)(J / tiles_f) * 8;        // sample tiles per round = partial rows
+        a.sched = nullptr;
+        if (stat_rows) *stat_rows = (int)(tiles_m < slots ? tiles_m : slots);
+        hipLaunchKernelGGL((gemm_nt256p_kernel<EPI, 4, false>), dim3(8 * J), dim3(512), 0, st, a);
+    }
     return hipGetLastError();
 }

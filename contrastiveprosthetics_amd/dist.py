@@ -26,6 +26,16 @@ def rank() -> int:
     return td.get_rank() if td.is_available() and td.is_initialized() else 0
 
 
+def share_gpu_with_other_kernels():
+    """Tell the library that its GEMM launches will run beside other kernels on the same GPU -- RCCL's collectives on
+    their own streams at world size > 1, or neighbour processes in a packed sweep: tiles are then drawn dynamically
+    (cp_set_tile_schedule, include/cpnative.h) unless $CPNATIVE_TILE_SCHEDULE says otherwise."""
+    if os.environ.get("CPNATIVE_TILE_SCHEDULE") or not torch.cuda.is_available():
+        return
+    from . import _lib
+    _lib.check(_lib.load().cp_set_tile_schedule(1), "cp_set_tile_schedule")
+
+
 def init_from_env(backend: str = None) -> Tuple[int, int]:
     """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  No-op for 1 process."""
     w = int(os.environ.get("WORLD_SIZE", "1"))
@@ -43,6 +53,7 @@ def init_from_env(backend: str = None) -> Tuple[int, int]:
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         td.init_process_group(backend)
+    share_gpu_with_other_kernels()
     return rank(), world_size()
 
 
@@ -99,6 +110,8 @@ def init_packed_from_env():
     dev = local % n_dev if n_dev else 0
     if w > 1 and not td.is_initialized():
         td.init_process_group("gloo")
+    if w > 1:
+        share_gpu_with_other_kernels()
     return rank(), world_size(), dev
 
 

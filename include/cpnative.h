@@ -91,6 +91,17 @@ typedef struct cp_step_state {
 int cp_version(void);
 const char* cp_last_error(void);
 
+/* How the persistent fc GEMM kernels (14 launches per step) hand their output tiles to the CUs; process-wide,
+ * read at every launch.  CP_TILES_STATIC: each workgroup owns a fixed list of tiles -- fastest when this process
+ * has the GPU to itself.  CP_TILES_DYNAMIC: workgroups draw tiles from per-XCD counters -- 2-4 % slower alone, but
+ * a launch that shares CUs with another stream's or process's kernels (RCCL collectives at world size > 1, a
+ * packed sweep) no longer waits for its latest-starting workgroup (+35 % with 8-32 CUs held).  BatchNorm partial
+ * sums are grouped per sample tile in the dynamic mode and per workgroup in the static one, so the two differ in
+ * the last bits; each is run-to-run reproducible.  Default: static, or $CPNATIVE_TILE_SCHEDULE (static|dynamic). */
+enum { CP_TILES_STATIC = 0, CP_TILES_DYNAMIC = 1 };
+int cp_set_tile_schedule(int32_t mode);
+int cp_get_tile_schedule(void);
+
 /* bytes of scratch needed by the calls below for up to `max_windows` encoder rows */
 size_t cp_workspace_bytes(int64_t max_windows, int32_t dtype, float dp_emg);
 

@@ -29,7 +29,7 @@ def gemm(dbg=0):
 
 
 for hog in (0, 8, 16, 32):
-    for dbg, name in ((0, "persistent"), (24, "one tile per block")):
+    for dbg, name in ((128, "persistent, static tiles"), (64, "persistent, dynamic tiles"), (24, "one tile per block")):
         ts = []
         for _ in range(5):
             torch.cuda.synchronize()
@@ -43,4 +43,4 @@ for hog in (0, 8, 16, 32):
             e1.record(main)
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 4 * 1e3)
-        print(f"{hog:3d} CUs held elsewhere, {name:18s}: {sorted(ts)[2]:7.1f} us per launch")
+        print(f"{hog:3d} CUs held elsewhere, {name:26s}: {sorted(ts)[2]:7.1f} us per launch")
