@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--cpu_seconds", type=float, default=15.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel-kind times to stderr")
+    ap.add_argument("--profile_every", type=int, default=4,
+                    help="bracket the fc GEMM launches with HIP events (the live roofline numbers) on every n-th timed step")
     ap.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],
                     help="glove = BASELINE config 3 (glove-angle class encoder); the default line is config 1 (one-hot)")
     args = ap.parse_args()
@@ -211,6 +213,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        # the live per-kernel timing brackets each fc GEMM launch with two HIP events, and every event record idles
+        # the queue for ~5 us (58 of them per step = 6 % of it): sample every --profile_every-th step
+        if i % args.profile_every == 0:
+            eng.profile_resume()
+        else:
+            eng.profile_disable()
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0

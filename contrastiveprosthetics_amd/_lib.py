@@ -86,6 +86,7 @@ SYMBOLS = {
     "cp_get_tile_schedule": (C.c_int, []),
     "cp_profile_enable": (C.c_int, [C.c_uint64, C.c_int32]),
     "cp_profile_disable": (C.c_int, []),
+    "cp_profile_resume": (C.c_int, []),
     "cp_profile_summary": (C.c_int, [C.c_int32, _P(C.c_double), _P(C.c_int64)]),
     "cp_debug_activation": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, C.c_int32, _fp, _fp]),
     "cp_debug_bn_stats": (C.c_int, [_P(cp_config), _fp, C.c_size_t, C.c_int32, _fp, _fp]),

@@ -103,6 +103,11 @@ extern "C" int cp_profile_enable(uint64_t kind_mask, int32_t max_records) {
     return 0;
 }
 extern "C" int cp_profile_disable(void) { g_prof.on = false; return 0; }
+extern "C" int cp_profile_resume(void) {
+    if (!g_prof.cap) return fail(CP_ERR_ARG, "cp_profile_resume before cp_profile_enable");
+    g_prof.on = true;
+    return 0;
+}
 extern "C" int cp_profile_summary(int32_t kind, double* total_ms, int64_t* count) {
     // caller has synchronised the stream
     if (!total_ms || !count) return fail(CP_ERR_ARG, "cp_profile_summary args");

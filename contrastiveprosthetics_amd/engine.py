@@ -437,6 +437,10 @@ class Engine:
     def profile_disable(self):
         self.lib.cp_profile_disable()
 
+    def profile_resume(self):
+        """Record again after profile_disable without dropping the records taken so far."""
+        _lib.check(self.lib.cp_profile_resume(), "cp_profile_resume")
+
     def profile_summary(self) -> Dict[str, Tuple[float, int]]:
         """{kind: (total ms, launches)} of the records taken since profile_enable; sync first."""
         torch.cuda.synchronize(self.device)

@@ -250,6 +250,9 @@ enum {
 };
 int cp_profile_enable(uint64_t kind_mask, int32_t max_records);
 int cp_profile_disable(void);
+/* records again after cp_profile_disable, keeping what was recorded (sampling every n-th step: each recorded launch costs
+ * two event records, ~5 us of idle queue apiece) */
+int cp_profile_resume(void);
 int cp_profile_summary(int32_t kind, double* total_ms, int64_t* count);
 
 /* debug/test access: copy saved activation `layer` (0..8 = post-ReLU pre-BN output of conv1,
