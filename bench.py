@@ -35,11 +35,12 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
 # profiler kind -> (the ONE kernel it times, as rocprofv3 names it; fc layer indices it runs on when dropout is on / off)
+# ({dyn} = the tile schedule, include/cpnative.h cp_set_tile_schedule: "false" static, "true" dynamic)
 GEMM_KERNELS = {
-    "fc_fwd": "gemm_nt256p_kernel<0, 4>",          # persistent, bias + ReLU + BN sums in the epilogue
-    "fc_dgrad": "gemm_nt256p_kernel<1, 4>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
-    "fc_dgrad_bn": "gemm_nt256p_kernel<3, 4>",     # persistent, + BN/ReLU backward of the layer below against the saved activation
-    "fc_dgrad_stats": "gemm_nt256p_kernel<4, 4>",  # persistent, behind a dropout: mask + BN-backward sums against the saved activation
+    "fc_fwd": "gemm_nt256p_kernel<0, 4, {dyn}>",          # persistent, bias + ReLU + BN sums in the epilogue
+    "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
+    "fc_dgrad_bn": "gemm_nt256p_kernel<3, 4, {dyn}>",     # persistent, + BN/ReLU backward of the layer below against the saved activation
+    "fc_dgrad_stats": "gemm_nt256p_kernel<4, 4, {dyn}>",  # persistent, behind a dropout: mask + BN-backward sums against the saved activation
     "fc_wgrad": "gemm_tn256_kernel",
 }
 
@@ -222,6 +223,7 @@ def main():
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    profiled_steps = len(range(0, args.steps, args.profile_every))
     eng.profile_disable()
     prof = eng.profile_summary()
     if use_dist:
@@ -253,7 +255,8 @@ def main():
         # HBM bytes per launch from the committed PMC profile of this same command (tools/parse_profile.py,
         # separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction); null if not profiled
         traffic = None
-        kname = GEMM_KERNELS[dom]
+        dyn = "true" if eng.lib.cp_get_tile_schedule() else "false"
+        kname = GEMM_KERNELS[dom].format(dyn=dyn)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if args.dtype == "bf16" and B == 4096 and os.path.exists(tpath):
             for k, v in json.load(open(tpath))["kernels"].items():
@@ -264,7 +267,7 @@ def main():
             if k in prof and prof[k][1] > 0:
                 kb, kf = gemm_model(k, N, es, args.dp_emg > 0)
                 ks_ = prof[k][0] / prof[k][1] / 1e3
-                per_kernel[k] = dict(symbol=GEMM_KERNELS[k], launches=prof[k][1], avg_us=ks_ * 1e6, algorithmic_bytes=kb,
+                per_kernel[k] = dict(symbol=GEMM_KERNELS[k].format(dyn=dyn), launches=prof[k][1], avg_us=ks_ * 1e6, algorithmic_bytes=kb,
                                      gbs=kb / ks_ / 1e9, hbm_frac=kb / ks_ / 1e9 / HBM_PEAK_GBS, tflops=kf / ks_ / 1e12)
         bound = "hbm" if byts / (HBM_PEAK_GBS * 1e9) >= flops / (mfma_peak * 1e12) else "mfma"
         roof = dict(bound=bound, kernel=dom, kernel_symbol=kname, launches=launches, avg_us=avg_s * 1e6,
@@ -273,7 +276,8 @@ def main():
                     frac=(gbs / HBM_PEAK_GBS) if bound == "hbm" else (tfl / mfma_peak), traffic=traffic,
                     algorithmic_bytes=byts,
                     mfma_tflops=tfl, mfma_frac=tfl / mfma_peak, hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
-                    gemm_ms_per_step={k: prof[k][0] / args.steps for k in gemm_kinds if k in prof},
+                    gemm_ms_per_step={k: prof[k][0] / profiled_steps for k in gemm_kinds if k in prof},
+                    profiled_steps=profiled_steps,
                     per_kernel=per_kernel)
         rec = dict(metric="sEMG windows/sec contrastive step, 12-ch Ninapro, 1/2/4/8 MI355X", value=world * N * args.steps / elapsed,
                    unit="windows/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
