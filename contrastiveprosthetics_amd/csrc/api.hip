@@ -1060,7 +1060,7 @@ static int launch_norms(OptArgs& a, float* scratch, float* l2_out, hipStream_t s
     a.norms = scratch + a.total_chunks;
     a.l2_out = l2_out;
     hipLaunchKernelGGL(l2_sumsq_kernel, dim3(a.total_chunks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(l2_finalize_kernel, dim3(1), dim3(CP_MAX_TENSORS), 0, st, a);
+    hipLaunchKernelGGL(l2_finalize_kernel, dim3(1), dim3(L2_FIN_LANES * CP_MAX_TENSORS), 0, st, a);
     CKL("l2 norms");
     return 0;
 }

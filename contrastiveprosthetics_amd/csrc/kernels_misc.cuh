@@ -38,13 +38,13 @@ __global__ void gather_groups_kernel(const float* __restrict__ table, const int6
 // stats out: [4][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
 // ------------------------------------------------------------------------------------
 // (finalize kernels: FIN_COLS columns x FIN_LANES row lanes per block of FIN_THREADS, FIN_GRID(C) blocks: up to
-//  FIN_DIRECT_ROWS partial rows -- 12 per lane -- are folded here directly, without a reduce_rows_kernel launch first.
+//  FIN_DIRECT_ROWS partial rows -- 32 per lane -- are folded here directly, without a reduce_rows_kernel launch first.
 //  With 64 columns x 16 row lanes the 512-column layers ran on 8 blocks and 656 rows took 9-16 us.)
 #define FIN_THREADS 1024
 #define FIN_COLS 16
 #define FIN_LANES (FIN_THREADS / FIN_COLS)
 #define FIN_GRID(C) (((C) + FIN_COLS - 1) / FIN_COLS)
-#define FIN_DIRECT_ROWS 768
+#define FIN_DIRECT_ROWS 2048
 // sum over the block's row lanes of one value per thread (thread = column cl + FIN_COLS * row lane): the four row
 // lanes of a wave by shuffles, the 16 waves through red; valid in the threads tid < FIN_COLS
 __device__ __forceinline__ double fin_block_sum(double s, double (*red)[FIN_COLS], int tid) {

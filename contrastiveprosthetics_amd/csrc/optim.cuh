@@ -57,20 +57,28 @@ __global__ __launch_bounds__(256) void l2_sumsq_kernel(OptArgs a) {
     if (threadIdx.x == 0) a.norm_partials[chunk] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void l2_finalize_kernel(OptArgs a) {
+// one block of 16 * CP_MAX_TENSORS threads: 16 lanes per tensor walk its chunk sums (a weight matrix has 128-192 of
+// them; one thread per tensor took 18-20 us), folded in a fixed order
+#define L2_FIN_LANES 16
+__global__ __launch_bounds__(L2_FIN_LANES * CP_MAX_TENSORS) void l2_finalize_kernel(OptArgs a) {
     __shared__ double contrib[CP_MAX_TENSORS];
-    const int i = threadIdx.x;
-    double c = 0;
-    if (i < a.n_tensors) {
-        double s = 0;
-        for (int k = 0; k < a.t[i].nchunks; ++k) s += (double)a.norm_partials[a.t[i].chunk0 + k];
-        const float n = (float)sqrt(s);
-        a.norms[i] = n;
-        if (a.t[i].l2) c = (double)a.reg[a.t[i].group] * (double)n;
+    const int i = threadIdx.x / L2_FIN_LANES, l = threadIdx.x % L2_FIN_LANES;
+    double s = 0;
+    if (i < a.n_tensors)
+        for (int k = l; k < a.t[i].nchunks; k += L2_FIN_LANES) s += (double)a.norm_partials[a.t[i].chunk0 + k];
+#pragma unroll
+    for (int m = 1; m < L2_FIN_LANES; m <<= 1) s += __shfl_xor(s, m, 64);
+    if (l == 0) {
+        double c = 0;
+        if (i < a.n_tensors) {
+            const float n = (float)sqrt(s);
+            a.norms[i] = n;
+            if (a.t[i].l2) c = (double)a.reg[a.t[i].group] * (double)n;
+        }
+        contrib[i] = c;
     }
-    contrib[i] = c;
     __syncthreads();
-    if (i == 0) {
+    if (threadIdx.x == 0) {
         double s = 0;
         for (int k = 0; k < a.n_tensors; ++k) s += contrib[k];
         *a.l2_out = (float)s;

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-kernel totals of ONE training step from a rocprofv3 --kernel-trace run of bench.py (rocpd SQLite):
+   python tools/step_kernels.py <dir with *_results.db> [--timeline]"""
+import collections
+import glob
+import os
+import sqlite3
+import sys
+
+db = glob.glob(os.path.join(sys.argv[1], "**", "*_results.db"), recursive=True)[0]
+rows = list(sqlite3.connect(db).execute("select name, start, end, duration from kernels order by start"))
+idx = [i for i, r in enumerate(rows) if r[0].startswith("gather_groups")]
+a, b = idx[-2], idx[-1]
+tot = collections.defaultdict(lambda: [0, 0.0])
+for r in rows[a:b]:
+    n = r[0].split("(")[0].replace("void ", "")[:46]
+    tot[n][0] += 1
+    tot[n][1] += r[3] / 1e3
+    if "--timeline" in sys.argv:
+        print("%9.1f %8.1f us  %s" % ((r[1] - rows[a][1]) / 1e3, r[3] / 1e3, r[0][:80]))
+print("step span %.1f us, kernel time %.1f us, %d launches" % ((rows[b][1] - rows[a][1]) / 1e3, sum(v[1] for v in tot.values()), b - a))
+for n, v in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+    print("%-48s %3d  %8.1f us  avg %6.1f" % (n, v[0], v[1], v[1] / v[0]))
