@@ -176,6 +176,11 @@ def main():
         gm = torch.randn(T, 20, generator=g)
         glove_rows = (gm[None] + 0.3 * torch.randn(B, T, 20, generator=g)).to(dev)
 
+    reduce_grads = None
+    if use_dist:
+        from contrastiveprosthetics_amd.dist import GradAllReduce
+        reduce_grads = GradAllReduce(eng, force=True)
+
     def step(i):
         x = eng.gather(table, emg_rand, perms[i], 1)
         z = eng.encoder_forward(x, training=True)
@@ -195,7 +200,9 @@ def main():
             out, pred, _ = eng.head(z, labels, 1, want_grad=True)
             eng.encoder_backward(x)
         if use_dist:
-            dist.all_reduce(eng.grads.flat)          # one 8 MB sum; averaged by grad_scale inside Adam
+            # the 8 MB gradient sum in two buckets: everything but the conv stack's 0.15 MB starts behind an event the
+            # backward call records before its conv kernels (~0.5 ms of them); averaged by grad_scale inside Adam
+            reduce_grads()
         eng.adam_step(params, grad_scale=1.0 / world)
         if work is not None:
             work.wait()

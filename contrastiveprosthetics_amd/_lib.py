@@ -62,6 +62,7 @@ SYMBOLS = {
     "cp_head": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t,
                           _fp, _fp, _fp, _P(cp_params), _fp]),
     "cp_encoder_backward": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, _P(cp_params), _fp]),
+    "cp_encoder_backward_ev": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, _P(cp_params), _fp, _fp]),
     "cp_vote": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp]),
     "cp_subset_vote": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, _fp, _fp]),
     "cp_confusion": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp]),

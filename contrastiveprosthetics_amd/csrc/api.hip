@@ -771,7 +771,7 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
 
 template <typename T>
 static int encoder_backward_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
-                              cp_params* g, hipStream_t st) {
+                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready) {
     using D = DT<T>;
     const int64_t N = c->n_windows, R12 = N * 12;
     const bool drop = c->training && c->dp_emg > 0.f;
@@ -953,6 +953,9 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         }
         T* tmp = cur; cur = nxt; nxt = tmp;
     }
+    // every gradient but the conv stack's is final here (cp_encoder_backward_ev): a data-parallel caller starts summing
+    // them across ranks while the conv backward below still runs
+    if (fc_grads_ready) CK(hipEventRecord(fc_grads_ready, st));
     // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
     {
         if (!bn_done) {
@@ -1019,14 +1022,19 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     return 0;
 }
 
-extern "C" int cp_encoder_backward(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,
-                                   cp_params* grads, void* stream) {
+extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,
+                                      cp_params* grads, void* stream, void* fc_grads_ready) {
     WS w;
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !grads) return fail(CP_ERR_ARG, "cp_encoder_backward args");
     if (cfg->dtype == CP_BF16)
-        return encoder_backward_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream);
-    return encoder_backward_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream);
+        return encoder_backward_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
+    return encoder_backward_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
+}
+
+extern "C" int cp_encoder_backward(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,
+                                   cp_params* grads, void* stream) {
+    return cp_encoder_backward_ev(cfg, p, x, ws, ws_bytes, grads, stream, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------

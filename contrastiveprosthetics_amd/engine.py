@@ -353,12 +353,16 @@ class Engine:
                                               self._stream()), "cp_glove_backward")
 
     def encoder_backward(self, x: torch.Tensor):
+        """self.fc_grads_ready (a recorded-once torch.cuda.Event, or None; dist.GradAllReduce sets it) is recorded on the
+        stream when every gradient except the conv stack's is final (cp_encoder_backward_ev)."""
         x = x.reshape(-1, 12)
         n = x.shape[0]
         cfg = self._cfg(n, True)
         ws, nb = self._ws_args(n)
-        _lib.check(self.lib.cp_encoder_backward(C.byref(cfg), C.byref(self._p), x.data_ptr(), ws, nb, C.byref(self._g),
-                                                self._stream()), "cp_encoder_backward")
+        ev = getattr(self, "fc_grads_ready", None)
+        _lib.check(self.lib.cp_encoder_backward_ev(C.byref(cfg), C.byref(self._p), x.data_ptr(), ws, nb, C.byref(self._g),
+                                                   self._stream(), ev.cuda_event if ev is not None else None),
+                   "cp_encoder_backward")
 
     def vote(self, pred: torch.Tensor, labels: torch.Tensor, B: int, V: int):
         curve = torch.empty(B, V, dtype=torch.float32, device=self.device)

@@ -69,6 +69,7 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
     world, rank = (1, 0) if solo else (cpdist.world_size(), cpdist.rank())
     if world > 1:
         cpdist.broadcast_(model.engine.values.flat)
+        reduce_grads = cpdist.GradAllReduce(model.engine)     # two buckets, the large one beside the conv backward
     epochs = params["epochs"]
     dataset.set_train()
     model.set_train()
@@ -113,7 +114,7 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
             loss_train.append(loss.detach())          # no host sync inside the step (reference: loss.item())
             model.backward()                          # == (loss + model.l2()).backward()
             if world > 1:
-                cpdist.all_reduce_sum_(model.engine.grads.flat)
+                reduce_grads()                        # conv-stack bucket now, the rest already under way
             model.optimizer_step(grad_scale=1.0 / world)
             nwin += label.numel()
         acc_train = model.correct()

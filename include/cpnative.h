@@ -134,6 +134,13 @@ int cp_head(const cp_config* cfg, const cp_params* p, const float* z, const int6
  * consumes dL/dz left in ws by cp_head, writes every emg_net gradient into `grads`. */
 int cp_encoder_backward(const cp_config* cfg, const cp_params* p, const float* x, void* ws,
                         size_t ws_bytes, cp_params* grads, void* stream);
+/* The same, for data-parallel training: `fc_grads_ready` (a hipEvent_t, or NULL) is recorded on `stream` as soon as every
+ * gradient except the conv stack's (conv1, its BatchNorm, conv2, its BatchNorm -- 0.15 of the 8.1 MB) is final, about
+ * 0.5 ms before the call's last kernel at 167,936 windows: the caller's all-reduce of that part (torch.distributed /
+ * RCCL on another stream, after a wait on the event) runs beside the conv backward.  No reference counterpart: the
+ * reference is single-process (code/train.py:105). */
+int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, const float* x, void* ws,
+                           size_t ws_bytes, cp_params* grads, void* stream, void* fc_grads_ready);
 
 /* eval majority vote (code/models.py:151-163): pred (B,V,41) -> curve (B,V) of prefix-mode
  * accuracies, y_pred (B,41) = mode over all V samples. */
