@@ -1,0 +1,54 @@
+"""cp_encoder_backward_ev (include/cpnative.h): the caller's event is recorded when every gradient except the conv
+stack's is final.  A copy of that part of the flat gradient buffer taken on a side stream right behind the event must
+equal the buffer after the whole backward -- nothing that runs after the event may touch it -- and the gradients are
+those of the plain call."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = 41
+
+
+@pytest.mark.parametrize("dtype,dp", [("bf16", 0.0635), ("bf16", 0.0), ("f32", 0.0635)])
+def test_fc_gradients_are_final_at_the_event(dtype, dp):
+    from contrastiveprosthetics_amd.engine import Engine
+    n = 20000 - 20000 % T
+    g = torch.Generator().manual_seed(11)
+    mu = torch.randn(T, 12, generator=g)
+    x = (mu[None] + torch.randn(n // T, T, 12, generator=g)).reshape(n, 12).cuda()
+    labels = torch.arange(T).repeat(n // T).cuda()
+
+    def run(with_event):
+        e = Engine(adabn=False, dtype=dtype, dp_emg=dp, device="cuda", seed=123)
+        e.init_parameters(5)
+        e.grads.flat.fill_(float("nan"))                    # whatever is not written shows
+        split = e.grads.offsets["emg_net.linear.0.weight"][0]
+        snap = None
+        z = e.encoder_forward(x, training=True)
+        e.head(z, labels, 1, want_grad=True)
+        if with_event:
+            ev = torch.cuda.Event()
+            ev.record()
+            e.fc_grads_ready = ev
+            side = torch.cuda.Stream()
+            e.encoder_backward(x)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                snap = e.grads.flat[split:].clone()
+        else:
+            e.encoder_backward(x)
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in e.grads.views.items()}, e.grads.flat.clone(), split, snap
+
+    plain, _, split, _ = run(False)
+    views, flat, split2, snap = run(True)
+    assert split == split2 and 0 < split < flat.numel()
+    # final at the event (NaN padding between tensors included: nobody writes there either)
+    assert torch.equal(torch.nan_to_num(snap, nan=-7.0), torch.nan_to_num(flat[split:], nan=-7.0))
+    for k, v in views.items():
+        if not (k.startswith("emg_net.") or k.startswith("glove_net.easy.")):
+            continue                                        # glove-branch layers the one-hot path never uses: no gradient
+        assert torch.isfinite(v).all(), k                   # every gradient was written
+        assert torch.equal(v, plain[k]), k                  # and the call computes what the plain one does
+    # the conv stack is what is still being computed behind the event: it is the (small) front of the buffer
+    assert split * 4 < 0.2 * 2 ** 20
