@@ -17,9 +17,23 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint3
 __device__ __forceinline__ bf16_t f2bf(float f) {                   // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
     return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+// two f32 -> packed bf16 (one v_cvt_pk_bf16_f32); RELU: max(.,0) on the packed pair as signed 16-bit
+// integers (one v_pk_max_i16): a negative bf16, -0 included, is a negative int16, everything else keeps its bits
+template <bool RELU>
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    s16x2_t s = __builtin_bit_cast(s16x2_t, __builtin_convertvector(v, bf16x2_t));
+    if constexpr (RELU) {
+        const s16x2_t z = {0, 0};
+        s = __builtin_elementwise_max(s, z);
+    }
+    return __builtin_bit_cast(uint32_t, s);
 }
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return cvt_pk_bf16<false>(lo, hi); }
 
 // ---- per-dtype traits: a "chunk" is 16 bytes -----------------------------------
 template <typename T> struct DT;

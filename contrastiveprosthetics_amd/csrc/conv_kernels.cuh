@@ -51,26 +51,40 @@ template <typename T> struct ConvGeo {
 
 // conv1 for one (window, position) and the EPC channels of one chunk: value exactly as stored
 // activations are rounded (stats, BN-backward sums and conv2's input all see the same number)
+// xr = the window's 12 input values (global memory, or the strip's copy in LDS)
 template <typename T>
-__device__ __forceinline__ void conv1_chunk(const float* __restrict__ x, int64_t win, int w, const float (*wt)[3],
-                                            const float* bs, float* out) {
+__device__ __forceinline__ void conv1_chunk_row(const float* xr, int w, const float (*wt)[3], const float* bs, float* out) {
     using D = DT<T>;
     // unconditional loads at clamped positions + selects: no divergent branch around a load, so the
     // loads of several unrolled callers are issued back to back
-    const float* xr = x + win * 12;
     const float x0 = xr[w];
     const float xl = xr[w > 0 ? w - 1 : 0];
     const float xh = xr[w < 11 ? w + 1 : 11];
     const float xm = w > 0 ? xl : 0.f;
     const float xp = w < 11 ? xh : 0.f;
+    // channel pairs on the packed f32 pipe (v_pk_fma_f32: these kernels are bound by VALU issue, 4 cycles per wave64
+    // instruction); bf16: round first, ReLU on the packed pair (v_pk_max_i16) -- the same value as round(relu(y))
+    const f32x2_t xm2 = {xm, xm}, x02 = {x0, x0}, xp2 = {xp, xp};
 #pragma unroll
-    for (int e = 0; e < D::EPC; ++e) {
-        float y = bs[e];
-        y = fmaf(wt[e][0], xm, y);
-        y = fmaf(wt[e][1], x0, y);
-        y = fmaf(wt[e][2], xp, y);
-        out[e] = D::round(fmaxf(y, 0.f));
+    for (int e = 0; e < D::EPC; e += 2) {
+        f32x2_t y = {bs[e], bs[e + 1]};
+        y = __builtin_elementwise_fma((f32x2_t){wt[e][0], wt[e + 1][0]}, xm2, y);
+        y = __builtin_elementwise_fma((f32x2_t){wt[e][1], wt[e + 1][1]}, x02, y);
+        y = __builtin_elementwise_fma((f32x2_t){wt[e][2], wt[e + 1][2]}, xp2, y);
+        if constexpr (sizeof(T) == 2) {
+            const uint32_t pk = cvt_pk_bf16<true>(y.x, y.y);
+            out[e] = __uint_as_float(pk << 16);
+            out[e + 1] = __uint_as_float(pk & 0xffff0000u);
+        } else {
+            out[e] = fmaxf(y.x, 0.f);
+            out[e + 1] = fmaxf(y.y, 0.f);
+        }
     }
+}
+template <typename T>
+__device__ __forceinline__ void conv1_chunk(const float* __restrict__ x, int64_t win, int w, const float (*wt)[3],
+                                            const float* bs, float* out) {
+    conv1_chunk_row<T>(x + win * 12, w, wt, bs, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -84,22 +98,28 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restric
     constexpr int EPC = G::EPC, CPR = G::CPR, RPP = G::RPP;
     __shared__ float red[2][RPP][64];
     const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
-    float wt[EPC][3], bs[EPC], s1[EPC], s2[EPC];
+    float wt[EPC][3], bs[EPC];
+    f32x2_t s1[EPC / 2], s2[EPC / 2];                  // channel pairs (packed f32 adds / fmas)
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) wt[e][k] = w[(cc * EPC + e) * 9 + 3 + k];
         bs[e] = bias[cc * EPC + e];
-        s1[e] = s2[e] = 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < EPC / 2; ++k) s1[k] = s2[k] = (f32x2_t){0.f, 0.f};
     for (int64_t m = (int64_t)blockIdx.x * RPP + rr; m < rows; m += (int64_t)gridDim.x * RPP) {
         float v[EPC];
         conv1_chunk<T>(x, m / 12, (int)(m % 12), wt, bs, v);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+        for (int k = 0; k < EPC / 2; ++k) {
+            const f32x2_t vp = {v[2 * k], v[2 * k + 1]};
+            s1[k] += vp;
+            s2[k] = __builtin_elementwise_fma(vp, vp, s2[k]);
+        }
     }
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { red[0][rr][cc * EPC + e] = s1[e]; red[1][rr][cc * EPC + e] = s2[e]; }
+    for (int e = 0; e < EPC; ++e) { red[0][rr][cc * EPC + e] = s1[e / 2][e & 1]; red[1][rr][cc * EPC + e] = s2[e / 2][e & 1]; }
     __syncthreads();
     if (tid < 128) {
         const int which = tid >> 6, c = tid & 63;
@@ -152,6 +172,11 @@ __global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
     constexpr int W_BYTES = 64 * WPITCH;
     static_assert(REGION >= 2 * RPP * 64 * 4, "the end-of-kernel reduction reuses the image region");
     __shared__ __attribute__((aligned(16))) unsigned char smem[REGION + W_BYTES];
+    // MODE 0: the strip's raw input (16 windows x 12 values), double-buffered: the next strip's copy is requested at the
+    // start of a strip and parked here behind its MFMAs, so the image is built from LDS (per-row global loads of x sat,
+    // three at a time, in front of every image row's arithmetic: 153 -> 137 us).  MODE 1 recomputes r1 in its store-out
+    // loop, where the same change cost 38 us (128 -> 166): it keeps reading x from global memory.
+    __shared__ float xs[MODE == 0 ? 2 : 1][MODE == 0 ? CONV_WPB * 12 : 1];
     unsigned char* img = smem;
     unsigned char* Cs = smem;                      // aliases the image once the MFMAs are done
     unsigned char* Wl = smem + REGION;
@@ -185,12 +210,21 @@ __global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) b2v[q][e] = (MODE == 0) ? a.bias2[ft * 32 + 8 * q + 4 * h + e] : 0.f;
-    float s1[EPC], s2[EPC];
+    f32x2_t s1[EPC / 2], s2[EPC / 2];                // channel pairs (packed f32 adds / fmas)
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    for (int k = 0; k < EPC / 2; ++k) s1[k] = s2[k] = (f32x2_t){0.f, 0.f};
 
+    auto load_x = [&](int64_t strip) {
+        const int64_t i = strip * (CONV_WPB * 12) + tid;
+        return (tid < CONV_WPB * 12 && strip < nstrips && i < total_rows) ? a.x[i] : 0.f;
+    };
+    if (MODE == 0 && tid < CONV_WPB * 12) xs[0][tid] = load_x(blockIdx.x);
+    int xb = 0;
+    __syncthreads();
     for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
         const int64_t win0 = strip * CONV_WPB;
+        const float x_next = MODE == 0 ? load_x(strip + gridDim.x) : 0.f;
+        const float* xcur = xs[MODE == 0 ? xb : 0];
         // ---- stage the image: 16 windows x 14 rows x 64 channels ------------------------------
         // (fully unrolled: the CONV_IMG_ROWS / RPP independent global loads are issued together)
         {
@@ -206,7 +240,7 @@ __global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
                 const int wpos = ok ? wp - 1 : 0;
                 if constexpr (MODE == 0) {
                     float t[EPC];
-                    conv1_chunk<T>(a.x, winc, wpos, wt, bs, t);
+                    conv1_chunk_row<T>(xcur + nl * 12, wpos, wt, bs, t);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
                     v[it] = D::pack(t);
@@ -241,6 +275,7 @@ __global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
                 mma_chunk<T>(fw, fs, acc[j]);
             }
         }
+        if (MODE == 0 && tid < CONV_WPB * 12) xs[xb ^ 1][tid] = x_next;     // read from the next strip on, two barriers away
         __syncthreads();                           // image dead: the region becomes the output tile
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -248,16 +283,19 @@ __global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int fl = ft * 32 + 8 * q + 4 * h;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float xv = acc[j][4 * q + e];
-                    if constexpr (MODE == 0) xv = fmaxf(xv + b2v[q][e], 0.f);
-                    v[e] = xv;
+                f32x2_t v0 = {acc[j][4 * q], acc[j][4 * q + 1]}, v1 = {acc[j][4 * q + 2], acc[j][4 * q + 3]};
+                if constexpr (MODE == 0) {
+                    v0 += (f32x2_t){b2v[q][0], b2v[q][1]};
+                    v1 += (f32x2_t){b2v[q][2], b2v[q][3]};
                 }
                 unsigned char* dst = Cs + srow * CPITCH + fl * (int)sizeof(T);
-                if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (sizeof(T) == 2) {
+                    // bf16: round, then ReLU on the packed pair -- the same value as round(relu(.))
+                    *(uint2*)dst = make_uint2(cvt_pk_bf16<MODE == 0>(v0.x, v0.y), cvt_pk_bf16<MODE == 0>(v1.x, v1.y));
+                } else {
+                    if constexpr (MODE == 0) { v0 = __builtin_elementwise_max(v0, (f32x2_t){0.f, 0.f}); v1 = __builtin_elementwise_max(v1, (f32x2_t){0.f, 0.f}); }
+                    *(float4*)dst = make_float4(v0.x, v0.y, v1.x, v1.y);
+                }
             }
         }
         __syncthreads();
@@ -270,23 +308,31 @@ __global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
             const int64_t mc = ok ? m : 0;                      // loads unconditional, only the store is guarded
             const uint4 c = *(const uint4*)(Cs + row * CPITCH + cc * 16);
             float v[EPC];
-            D::unpack(c, v);
-            const float keep = ok ? 1.f : 0.f;
+            D::unpack(ok ? c : make_uint4(0, 0, 0, 0), v);      // rows past the end count as zeros
             if constexpr (MODE == 0) {
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) { s1[e] = fmaf(keep, v[e], s1[e]); s2[e] = fmaf(keep * v[e], v[e], s2[e]); }
+                for (int k = 0; k < EPC / 2; ++k) {
+                    const f32x2_t vp = {v[2 * k], v[2 * k + 1]};
+                    s1[k] += vp;
+                    s2[k] = __builtin_elementwise_fma(vp, vp, s2[k]);
+                }
             } else {
                 float r1[EPC];
                 conv1_chunk<T>(a.x, mc / 12, (int)(mc % 12), wt, bs, r1);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) { s1[e] = fmaf(keep, v[e], s1[e]); s2[e] = fmaf(keep * v[e], r1[e], s2[e]); }
+                for (int k = 0; k < EPC / 2; ++k) {
+                    const f32x2_t vp = {v[2 * k], v[2 * k + 1]}, rp = {r1[2 * k], r1[2 * k + 1]};
+                    s1[k] += vp;
+                    s2[k] = __builtin_elementwise_fma(vp, rp, s2[k]);
+                }
             }
             if (ok) *(uint4*)((T*)a.out + m * 64 + cc * EPC) = c;
         }
         __syncthreads();                           // output tile dead before the next image is staged
+        xb ^= 1;
     }
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { red[(0 * RPP + rr) * 64 + cc * EPC + e] = s1[e]; red[(1 * RPP + rr) * 64 + cc * EPC + e] = s2[e]; }
+    for (int e = 0; e < EPC; ++e) { red[(0 * RPP + rr) * 64 + cc * EPC + e] = s1[e / 2][e & 1]; red[(1 * RPP + rr) * 64 + cc * EPC + e] = s2[e / 2][e & 1]; }
     __syncthreads();
     if (tid < 128) {
         const int which = tid >> 6, c = tid & 63;

@@ -66,21 +66,7 @@ __device__ __forceinline__ float dpp_quad(float w) {
 // one 16-byte chunk of C.  (Non-temporal stores were measured: 203 vs 143 us forward, 195 vs 131 us data gradient --
 // the four chunks of a 128-byte line no longer merge in L2.)
 __device__ __forceinline__ void store_c16(bf16_t* p, const uint4& c) { *(uint4*)p = c; }
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef short s16x2_t __attribute__((ext_vector_type(2)));
-// two f32 -> packed bf16 (one v_cvt_pk_bf16_f32); RELU: max(.,0) on the packed pair as signed 16-bit
-// integers (one v_pk_max_i16): a negative bf16, -0 included, is a negative int16, everything else keeps its bits
-template <bool RELU>
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    const f32x2_t v = {lo, hi};
-    s16x2_t s = __builtin_bit_cast(s16x2_t, __builtin_convertvector(v, bf16x2_t));
-    if constexpr (RELU) {
-        const s16x2_t z = {0, 0};
-        s = __builtin_elementwise_max(s, z);
-    }
-    return __builtin_bit_cast(uint32_t, s);
-}
+// (cvt_pk_bf16<RELU>: common.cuh)
 
 // Register-direct epilogue of one tile (see gemm_nt256.cuh for the lane algebra): converts the accumulators
 // into 16-byte chunks (features i*32 + 8*(2kk + h) .. +7 of row mw0 + jj*32 + r; base = &C[mw0 + r][fw0 + 8h]),
