@@ -331,8 +331,9 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
     }
     // conv1
     {
-        constexpr int RPP = 256 / (64 / D::EPC);
-        const int g = grid_rows(R12, RPP, 2048);
+        constexpr int RPP = 256 / (64 / D::EPC);                      // windows per block and pass
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int g = (int)((need + passes - 1) / passes);            // every block makes the same number of passes
         {
             ProfScope ps(CP_K_CONV1_FWD, st);
             // statistics only: r1 is never stored, its consumers recompute it from x (conv_kernels.cuh)
@@ -1011,8 +1012,9 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(0), coef, g->bn_g[0],
                            g->bn_b[0], 64, 1);
         CKL("bn_bwd_finalize_kernel(conv1)");
-        constexpr int RPP = 256 / (64 / D::EPC);
-        const int gb = grid_rows(R12, RPP, 2048);
+        constexpr int RPP = 256 / (64 / D::EPC);                      // windows per block and pass
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int gb = (int)((need + passes - 1) / passes);           // every block makes the same number of passes
         hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, x, p->conv1_w, p->conv1_b, coef, partials, R12);
         nr = gb;
         pp = pre(nr, 4 * 64, 2 * REDUCE_SLICES);
