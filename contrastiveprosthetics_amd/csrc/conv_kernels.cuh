@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void conv1_materialize_kernel(const float* __r
 // the kernel needs 198-234 VGPRs; capping it at 168 for a third block (__launch_bounds__(256, 3)) spilled 30-61
 // registers and ran 2x slower (0.39 / 0.32 ms against 0.15 / 0.18 ms for forward / data gradient at 167,936 windows).
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void conv2_strip_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
     using D = DT<T>;
     using G = ConvGeo<T>;
     constexpr int EPC = G::EPC, CPR = G::CPR, ROWB = G::ROWB, RPP = G::RPP, WPITCH = G::WPITCH, CPITCH = G::CPITCH;
