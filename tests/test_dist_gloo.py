@@ -60,6 +60,17 @@ def _worker(rank, world, port, out_dir):
     gflat = _flat({k: m.sd[k].grad for k in gkeys}, gkeys).clone()
     local = gflat.clone()
     cpdist.all_reduce_sum_(gflat)
+    # the two-bucket reducer (conv stack | everything from fc1's weight on) gives the same sums
+    from collections import OrderedDict
+    from types import SimpleNamespace
+    offs, o = OrderedDict(), 0
+    for k in gkeys:
+        offs[k] = (o, m.sd[k].numel())
+        o += m.sd[k].numel()
+    eng = SimpleNamespace(grads=SimpleNamespace(flat=local.clone(), offsets=offs))
+    red = cpdist.GradAllReduce(eng)
+    assert 0 < red.split < local.numel() and not red.active
+    assert torch.equal(red(), gflat)
     gflat /= world
     torch.save(dict(local=local, mean=gflat, loss=loss.detach()), os.path.join(out_dir, f"r{rank}.pt"))
 
