@@ -978,12 +978,12 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         {
             ProfScope ps(CP_K_CONV2_WGRAD, st);
             const int64_t strips = (N + CONV_WG_WPB - 1) / CONV_WG_WPB;
-            const int64_t cap = sizeof(T) == 2 ? 768 : 256;      // 3 blocks per CU fit in LDS (44 KB) in bf16
+            const int64_t cap = sizeof(T) == 2 ? 512 : 256;      // two blocks per CU (194 registers with the strip prefetch)
             const int S = (int)(strips < cap ? strips : cap);
             ca.partials = slabs;
             hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
-            // up to 768 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
-            // unused tail of the slab buffer), then the scatter kernel walks 32 instead of 768
+            // up to 512 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
+            // unused tail of the slab buffer), then the scatter kernel walks 32 instead of 512
             const float* sl = slabs;
             int ns = S;
             if (S > 2 * REDUCE_SLICES) {

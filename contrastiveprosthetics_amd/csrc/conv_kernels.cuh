@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
 #define CONV_WG_WPB 8                                  // windows per strip of the weight-gradient kernel
 #define CONV_WG_IMG (CONV_WG_WPB * 14)                 // 112 image rows (a multiple of the 16-row k-step)
 template <typename T>
-__global__ __launch_bounds__(256) void conv2_wgrad_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
     using D = DT<T>;
     using G = ConvGeo<T>;
     constexpr int EPC = G::EPC, CPR = G::CPR, RPP = G::RPP, KSTEP = D::KSTEP;
@@ -405,36 +405,53 @@ __global__ __launch_bounds__(256) void conv2_wgrad_kernel(ConvArgs a) {
         *(uint4*)(Yi + 0 * PITCH + cc * 16) = make_uint4(0, 0, 0, 0);
         *(uint4*)(Yi + (ROWS - 1) * PITCH + cc * 16) = make_uint4(0, 0, 0, 0);
     }
+    // The strip's global loads (the gradient rows and the three inputs under conv1's taps, per image row of this thread)
+    // are requested one strip ahead, right behind the barrier that publishes the current images, and land under the
+    // MFMA phase: 28 more live registers (two blocks per CU instead of three), no exposed load latency.
+    uint4 xg[NIT];
+    float xr[NIT][3];
+    auto prefetch = [&](int64_t strip) {
+        const int64_t win0 = strip * CONV_WG_WPB;
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+            const int ir = rr + q * RPP;
+            const int nl = ir / 14, wp = ir % 14;
+            const int64_t win = win0 + nl;
+            const bool ok = strip < nstrips && ir < CONV_WG_IMG && wp >= 1 && wp <= 12 && win < a.n_windows;
+            const int64_t winc = ok ? win : 0;                     // clamped: loads are unconditional
+            const int wpos = ok ? wp - 1 : 0;
+            xg[q] = *(const uint4*)((const T*)a.gin + (winc * 12 + wpos) * 64 + cc * EPC);
+            const float* xw = a.x + winc * 12;
+            xr[q][0] = xw[wpos > 0 ? wpos - 1 : 0];
+            xr[q][1] = xw[wpos];
+            xr[q][2] = xw[wpos < 11 ? wpos + 1 : 11];
+        }
+    };
+    prefetch(blockIdx.x);
     for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
         const int64_t win0 = strip * CONV_WG_WPB;
         {
-            uint4 xv[NIT], yv[NIT];
-#pragma unroll
-            for (int q = 0; q < NIT; ++q) {                   // all gradient loads of the strip are issued together
-                const int ir = rr + q * RPP;
-                const int nl = ir / 14, wp = ir % 14;
-                const int64_t win = win0 + nl;
-                const bool ok = ir < CONV_WG_IMG && wp >= 1 && wp <= 12 && win < a.n_windows;
-                const int64_t winc = ok ? win : 0;                 // clamped: loads are unconditional
-                const int wpos = ok ? wp - 1 : 0;
-                xv[q] = *(const uint4*)((const T*)a.gin + (winc * 12 + wpos) * 64 + cc * EPC);
-                float t[EPC];
-                conv1_chunk<T>(a.x, winc, wpos, wt, bs, t);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
-                yv[q] = D::pack(t);
-                if (!ok) { xv[q] = make_uint4(0, 0, 0, 0); yv[q] = make_uint4(0, 0, 0, 0); }
-            }
 #pragma unroll
             for (int q = 0; q < NIT; ++q) {
                 const int ir = rr + q * RPP;
+                const int nl = ir / 14, wp = ir % 14;
+                const bool ok = ir < CONV_WG_IMG && wp >= 1 && wp <= 12 && win0 + nl < a.n_windows;
+                const int wpos = ok ? wp - 1 : 0;
+                float t[EPC];
+                conv1_chunk_vals<T>(wpos > 0 ? xr[q][0] : 0.f, xr[q][1], wpos < 11 ? xr[q][2] : 0.f, wt, bs, t);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
+                uint4 yv = D::pack(t);
+                uint4 xv = xg[q];
+                if (!ok) { xv = make_uint4(0, 0, 0, 0); yv = make_uint4(0, 0, 0, 0); }
                 if (ir < CONV_WG_IMG) {
-                    *(uint4*)(Xi + (ir + 1) * PITCH + cc * 16) = xv[q];
-                    *(uint4*)(Yi + (ir + 1) * PITCH + cc * 16) = yv[q];
+                    *(uint4*)(Xi + (ir + 1) * PITCH + cc * 16) = xv;
+                    *(uint4*)(Yi + (ir + 1) * PITCH + cc * 16) = yv;
                 }
             }
         }
         __syncthreads();
+        prefetch(strip + gridDim.x);
 #pragma unroll
         for (int k0 = 0; k0 < CONV_WG_IMG; k0 += KSTEP) {
             // image row j lives at LDS row j+1; the X row paired with Y image row j under tap t is image row j - t + 1
