@@ -235,6 +235,23 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
     };
     if (MODE == 0 && tid < CONV_WPB * 12) xs[0][tid] = load_x(blockIdx.x);
     int xb = 0;
+    // MODE 1: the strip's gradient rows (7 x 16 bytes per thread) are requested one strip ahead, behind the barrier that
+    // publishes the current image, and land under its MFMAs and epilogue
+    constexpr int NITG = CONV_IMG_ROWS / RPP;
+    uint4 pg[MODE == 1 ? NITG : 1];
+    auto prefetch_g = [&](int64_t strip) {
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int it = 0; it < NITG; ++it) {
+                const int ir = rr + it * RPP;
+                const int nl = ir / 14, wp = ir % 14;
+                const int64_t win = strip * CONV_WPB + nl;
+                const bool ok = strip < nstrips && wp >= 1 && wp <= 12 && win < a.n_windows;
+                pg[it] = *(const uint4*)((const T*)a.gin + ((ok ? win : 0) * 12 + (ok ? wp - 1 : 0)) * 64 + cc * EPC);
+            }
+        }
+    };
+    prefetch_g(blockIdx.x);
     __syncthreads();
     for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
         const int64_t win0 = strip * CONV_WPB;
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
                     for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
                     v[it] = D::pack(t);
                 } else {
-                    v[it] = *(const uint4*)((const T*)a.gin + (winc * 12 + wpos) * 64 + cc * EPC);
+                    v[it] = pg[it];
                 }
                 if (!ok) v[it] = make_uint4(0, 0, 0, 0);
             }
@@ -268,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
             for (int it = 0; it < NIT; ++it) *(uint4*)(img + G::img_off(rr + it * RPP, cc)) = v[it];
         }
         __syncthreads();
+        prefetch_g(strip + gridDim.x);
         // ---- implicit GEMM: out[m][f] = sum_tap sum_c image[row(m)+tap][c] * W[f][tap*64+c] ----
         f32x16 acc[3];
 #pragma unroll
