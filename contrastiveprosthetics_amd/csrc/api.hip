@@ -363,7 +363,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         if (drop && Lp >= 5) {
             T* u = (T*)(base + w.u[Lp - 5]);
             ProfScope ps(CP_K_DROPOUT, st);
-            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N * 512 / D::EPC, 256, 4096)), dim3(256), 0, st,
+            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N, 256 / (512 / D::EPC), 4096)), dim3(256), 0, st,
                                act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c));
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
@@ -394,7 +394,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         if (drop) {
             T* u = (T*)(base + w.u[Lp - 5]);
             ProfScope ps(CP_K_DROPOUT, st);
-            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N * 512 / D::EPC, 256, 4096)), dim3(256), 0, st,
+            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N, 256 / (512 / D::EPC), 4096)), dim3(256), 0, st,
                                act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c));
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
