@@ -146,9 +146,6 @@ def main():
             dist.init_process_group(rehearse)
         else:
             dist.init_process_group("nccl", device_id=dev)
-        # the collectives' kernels hold CUs while backward GEMMs run: dynamic tile schedule (include/cpnative.h)
-        from contrastiveprosthetics_amd.dist import share_gpu_with_other_kernels
-        share_gpu_with_other_kernels()
 
     from contrastiveprosthetics_amd.engine import Engine
 

@@ -94,8 +94,8 @@ const char* cp_last_error(void);
 /* How the persistent fc GEMM kernels (14 launches per step) hand their output tiles to the CUs; process-wide,
  * read at every launch.  CP_TILES_STATIC: each workgroup owns a fixed list of tiles -- fastest when this process
  * has the GPU to itself.  CP_TILES_DYNAMIC: workgroups draw tiles from per-XCD counters -- 2-4 % slower alone, but
- * a launch that shares CUs with another stream's or process's kernels (RCCL collectives at world size > 1, a
- * packed sweep) no longer waits for its latest-starting workgroup (+35 % with 8-32 CUs held).  BatchNorm partial
+ * a launch that shares CUs with another stream's or process's kernels (a packed sweep, collectives that stay
+ * resident for long) no longer waits for its latest-starting workgroup (+35 % with 8-32 CUs held).  BatchNorm partial
  * sums are grouped per sample tile in the dynamic mode and per workgroup in the static one, so the two differ in
  * the last bits; each is run-to-run reproducible.  Default: static, or $CPNATIVE_TILE_SCHEDULE (static|dynamic). */
 enum { CP_TILES_STATIC = 0, CP_TILES_DYNAMIC = 1 };
