@@ -36,6 +36,10 @@
 // +160..220 us per launch against the 94 us of the separate pass it replaced (which already streams at
 // 5.5 TB/s).
 //
+// Also measured: starting the XCDs 1.6 / 3.2 us apart, or the blocks of an XCD 6.4 us x (j & 3) apart, so that the
+// CUs' 128 KiB store bursts do not reach HBM together: no consistent change -- in the same process the same launch
+// moved between 133 and 155 us from one batch of 30 launches to the next (clock state), more than any of these.
+//
 // Also measured: staging through registers (global_load_dwordx4 at the start of a K step, ds_write_b128 at its end)
 // to avoid the LDS-DMA issue cost (8 issues per wave per K step, 100-185 cycles each beside ds_reads and MFMAs).  With
 // 128 accumulator + 48 fragment registers live there is no room for the 32 staging registers: hipcc parks them in
