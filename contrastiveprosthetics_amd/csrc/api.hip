@@ -860,6 +860,8 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     // bf16 only, and only where no dropout sits between the layers (the coefficients must exist before the launch:
     // they do when the BN-backward sums come from the weight gradient).  CPNATIVE_UNFUSED_BN_BWD (read per call)
     // keeps the separate pass, for the test that compares the two orders.
+    struct { const T* X; const T* Y; int i; } pend{};     // a weight gradient waiting for the next layer's (see defer_wgrad)
+    bool pending = false;
     for (int L = 8; L >= 2; --L) {
         const int i = L - 2, Lp = L - 1, K = fcK(i);
         if (!bn_done) {
@@ -881,11 +883,25 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         const float* s = in_drop ? nullptr : stats(Lp) + 2 * kLayerC[Lp];
         const float* t = in_drop ? nullptr : stats(Lp) + 3 * kLayerC[Lp];
         int S;
-        if constexpr (sizeof(T) == 2) {
+        // bf16, behind a dropout: this layer's BN-backward sums do not come from its weight gradient, so nothing needs
+        // the gradient before the optimiser.  fc7's and fc5's are deferred by one layer and run in ONE launch with the
+        // next layer's (the gradient buffer they read is the ping-pong partner, untouched until that layer's data
+        // gradient): two problems x 4 tiles x 32 splits fill the GPU with half the f32 slabs per layer (134 -> 67 MB
+        // written and re-read).
+        const bool defer_wgrad = sizeof(T) == 2 && in_drop && (i == 6 || i == 4) && fcK(i - 1) == 512 && !getenv("CPNATIVE_UNPAIRED_WGRAD");
+        if (defer_wgrad) {
+            pend.X = cur; pend.Y = Y; pend.i = i;
+            pending = true;
+        } else if constexpr (sizeof(T) == 2) {
             // 256x256 tiles: 4 (K=512) or 6 (K=768) tiles x ~256/tiles splits = one block per CU
             GemmTN256Args ta{};
-            ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
-            split_rows(N, K == 512 ? 64 : 40, &S, &ta.rows_per_split);
+            ta.X = (const bf16_t*)cur; ta.ldx = 512; ta.Y = (const bf16_t*)Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
+            if (pending) {
+                ta.X2 = (const bf16_t*)pend.X; ta.Y2 = (const bf16_t*)pend.Y; ta.slabs2 = slabs + (size_t)32 * 512 * 512;
+                split_rows(N, 32, &S, &ta.rows_per_split);
+            } else {
+                split_rows(N, K == 512 ? 64 : 40, &S, &ta.rows_per_split);
+            }
             ta.splits = S;
             ProfScope ps(CP_K_FC_WGRAD, st);
             CK(launch_gemm_tn256(ta, st));
@@ -896,9 +912,16 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             ProfScope ps(CP_K_FC_WGRAD, st);
             CK((launch_gemm_tn<T, 128, 128, YLOAD_PLAIN>(ta, S, st)));
         }
-        {
+        if (!defer_wgrad) {
             ProfScope ps(CP_K_REDUCE_SLABS, st);
             float* praw = (float*)(base + w.praw);
+            if (pending) {
+                // the deferred layer (always behind a dropout: no BN fold to undo, no raw product wanted)
+                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
+                                   (const float*)nullptr, (const float*)nullptr, g->fc_b[pend.i], g->fc_w[pend.i], 0, (float*)nullptr);
+                CKL("reduce_slabs(fc, deferred)");
+                pending = false;
+            }
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
                                i == 0 ? 1 : 0, in_drop ? (float*)nullptr : praw);
             CKL("reduce_slabs(fc)");

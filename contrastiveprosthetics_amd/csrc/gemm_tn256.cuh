@@ -27,6 +27,11 @@ struct GemmTN256Args {
     int64_t M;
     int64_t rows_per_split;   // multiple of 32
     int ldx, ldy, P, Q, splits;
+    // optional second problem of the same shape in the same launch (X2 != nullptr): two layers' weight gradients share
+    // the GPU, each with half the splits -- half the slab bytes written here and re-read by reduce_slabs_kernel
+    const bf16_t* X2;
+    const bf16_t* Y2;
+    float* slabs2;
 };
 
 __device__ __forceinline__ uint4 tn256_frag(const unsigned char* tile, int m_off, int col0, int lane) {
@@ -52,7 +57,12 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
     const int tiles_q = a.Q / 256, ntiles = (a.P / 256) * tiles_q;
     // bid = xcd + 8 * (tile + ntiles * (split / 8)),  split = 8 * (..) + xcd
     const int xcd = blockIdx.x & 7;
-    const int j = blockIdx.x >> 3;
+    int j = blockIdx.x >> 3;
+    const int per_problem = ntiles * ((a.splits + 7) / 8);
+    const bool second = j >= per_problem;              // block-uniform
+    if (second) j -= per_problem;
+    const bf16_t* __restrict__ Xg = second ? a.X2 : a.X;
+    const bf16_t* __restrict__ Yg = second ? a.Y2 : a.Y;
     const int tile = j % ntiles;
     const int split = (j / ntiles) * 8 + xcd;
     if (split >= a.splits) return;
@@ -77,8 +87,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
             int64_t m = ms + row;
             if (m >= me) m = me - 1;                   // rows past the end are zeroed by the caller's contract below
             const int colb = (((pb ^ (row & 3)) << 6) | (sub << 4)) >> 1;   // logical column (elements)
-            glds16(a.X + m * a.ldx + p0 + colb, Xs + inst * 1024);
-            glds16(a.Y + m * a.ldy + q0 + colb, Ys + inst * 1024);
+            glds16(Xg + m * a.ldx + p0 + colb, Xs + inst * 1024);
+            glds16(Yg + m * a.ldy + q0 + colb, Ys + inst * 1024);
         }
     };
 
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
         }
     }
 
-    float* slab = a.slabs + (int64_t)split * a.P * a.Q;
+    float* slab = (second ? a.slabs2 : a.slabs) + (int64_t)split * a.P * a.Q;
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -155,6 +165,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
 static inline hipError_t launch_gemm_tn256(const GemmTN256Args& a, hipStream_t st) {
     const int ntiles = (a.P / 256) * (a.Q / 256);
     const int groups = (a.splits + 7) / 8;
-    hipLaunchKernelGGL(gemm_tn256_kernel, dim3((unsigned)(groups * 8 * ntiles)), dim3(512), 0, st, a);
+    const int problems = a.X2 ? 2 : 1;
+    hipLaunchKernelGGL(gemm_tn256_kernel, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a);
     return hipGetLastError();
 }

@@ -84,3 +84,40 @@ def test_persistent_r_epilogue_equals_staged_r_epilogue(dp, monkeypatch):
         cos = float(a @ b / (a.norm() * b.norm()))
         rel = float((a - b).norm() / b.norm())
         assert cos > 0.9995 and rel < 3e-2, (k, cos, rel)
+
+
+def test_paired_weight_gradients_equal_unpaired(monkeypatch):
+    """bf16 with dropout: the weight gradients of fc7/fc6 and fc5/fc4 run as two problems of one launch with 32 splits
+    each (api.hip, defer_wgrad) -- against one launch per layer with 64 splits (CPNATIVE_UNPAIRED_WGRAD).  Same products,
+    f32 partial sums grouped differently."""
+    from contrastiveprosthetics_amd.engine import Engine
+    n = 40000 - 40000 % T
+    g = torch.Generator().manual_seed(6)
+    mu = torch.randn(T, 12, generator=g)
+    x = (mu[None] + torch.randn(n // T, T, 12, generator=g)).reshape(n, 12).cuda()
+    labels = torch.arange(T).repeat(n // T).cuda()
+    grads = []
+    for unpaired in (False, True):
+        if unpaired:
+            monkeypatch.setenv("CPNATIVE_UNPAIRED_WGRAD", "1")
+        else:
+            monkeypatch.delenv("CPNATIVE_UNPAIRED_WGRAD", raising=False)
+        e = Engine(adabn=False, dtype="bf16", dp_emg=0.0635, device="cuda", seed=123)
+        e.init_parameters(8)
+        e.grads.flat.zero_()
+        z = e.encoder_forward(x, training=True)
+        e.head(z, labels, 1, want_grad=True)
+        e.encoder_backward(x)
+        torch.cuda.synchronize()
+        grads.append({k: e.grads.views[k].clone() for k in e.specs})
+    from contrastiveprosthetics_amd.engine import LINEAR_IDX
+    behind_dropout = {f"emg_net.linear.{LINEAR_IDX[i]}.weight" for i in (4, 5, 6)} | {"emg_net.last.0.weight"}
+    for k in grads[0]:
+        a, b = grads[0][k].double().flatten(), grads[1][k].double().flatten()
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        rel = float((a - b).norm() / b.norm())
+        # fc5..fc7: f32 sums of the same bf16 products, regrouped.  Below them the regrouped product of fc4 feeds fc3's
+        # BatchNorm-backward sums (bn_bwd_sums_from_wgrad), so the gradient that flows on differs in its last bits.
+        assert rel < (1e-5 if k in behind_dropout else 2e-3), (k, rel)
