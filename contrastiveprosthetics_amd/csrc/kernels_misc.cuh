@@ -161,18 +161,32 @@ __global__ void transpose_w_kernel(const float* __restrict__ W, T* __restrict__ 
 // of the backward pass (8 launches of ~5 us each otherwise)
 struct TransposeJob { const float* W; void* out; int F, K, ld_out, mode; };
 struct TransposeBatch { TransposeJob job[8]; };
+// 64 x 64 tiles through LDS: rows of W are read along k (coalesced f32), rows of the output are written along j
+// (coalesced T).  grid (max tiles of a job, jobs), 256 threads.  (The first version read W with a stride of K floats
+// between neighbouring threads and divided a 64-bit index per element: 16.6 us for the eight matrices, now 11.5.)
 template <typename T>
-__global__ void transpose_w_batch_kernel(TransposeBatch b) {
+__global__ __launch_bounds__(256) void transpose_w_batch_kernel(TransposeBatch b) {
     using D = DT<T>;
+    __shared__ float tile[64][65];
     const TransposeJob j = b.job[blockIdx.y];
-    const int64_t total = (int64_t)j.K * j.ld_out;
+    const int tiles_j = j.ld_out / 64, tiles_k = j.K / 64;
     T* out = (T*)j.out;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % j.ld_out);
-        const int kp = (int)(i / j.ld_out);
-        int k = kp;
-        if (j.mode == 1) k = (kp & 63) * 12 + (kp >> 6);
-        D::store(out + i, col < j.F ? j.W[(int64_t)col * j.K + k] : 0.f);
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < tiles_j * tiles_k; t += gridDim.x) {
+        const int j0 = (t % tiles_j) * 64, k0 = (t / tiles_j) * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = grp + 4 * r;
+            tile[jj][lane] = (j0 + jj) < j.F ? j.W[(int64_t)(j0 + jj) * j.K + k0 + lane] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = grp + 4 * r, k = k0 + kk;
+            const int kp = j.mode == 1 ? (k % 12) * 64 + k / 12 : k;       // fc1: internal order k' = w*64 + c of k = c*12 + w
+            D::store(out + (int64_t)kp * j.ld_out + j0 + lane, tile[lane][kk]);
+        }
+        __syncthreads();
     }
 }
 
