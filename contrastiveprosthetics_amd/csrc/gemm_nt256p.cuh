@@ -36,6 +36,10 @@
 // +160..220 us per launch against the 94 us of the separate pass it replaced (which already streams at
 // 5.5 TB/s).
 //
+// Also measured: F = 768 (fc1's data gradient: 3 column tiles, so the static form runs 30 blocks per XCD and 9 rounds)
+// through the per-tile code path with round-robin items on all 32 blocks (8 rounds): that launch 19 us faster (-8 %),
+// the step unchanged -- its 656 x 12 partial rows of 64 channels cost the reduction kernels what the launch gained.
+//
 // Also measured: starting the XCDs 1.6 / 3.2 us apart, or the blocks of an XCD 6.4 us x (j & 3) apart, so that the
 // CUs' 128 KiB store bursts do not reach HBM together: no consistent change -- in the same process the same launch
 // moved between 133 and 155 us from one batch of 30 launches to the next (clock state), more than any of these.
