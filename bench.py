@@ -194,8 +194,8 @@ def main():
         if glove_rows is not None:
             zg = eng.glove_forward(glove_rows, training=True)
             out, pred, _ = eng.head_glove(z, zg, labels, 1, want_grad=True)
+            eng.glove_backward()             # first: its gradients sit in the bucket that encoder_backward's event releases
             eng.encoder_backward(x)
-            eng.glove_backward()
         else:
             out, pred, _ = eng.head(z, labels, 1, want_grad=True)
             eng.encoder_backward(x)

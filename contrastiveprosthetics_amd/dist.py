@@ -84,6 +84,8 @@ class GradAllReduce:
     flat buffer from the first fc weight on, 7.9 of 8.1 MB); that part is summed on a side stream behind the event,
     while conv2's and conv1's backward kernels (~0.5 ms at 167,936 windows) still run.  The 0.15 MB in front of it
     follows when the backward is complete.  Element-wise the result is that of one all-reduce of the whole buffer.
+    Whatever else writes into the large bucket (the glove-angle class encoder's backward) has to be enqueued BEFORE
+    engine.encoder_backward.
     Collectives are issued in the same order on every rank."""
 
     def __init__(self, engine, force: bool = False):

@@ -541,8 +541,8 @@ class GraphStep:
         if self.glove is not None:
             zg = e.glove_forward(self.glove(self.perm), training=True)
             out, pred, _ = e.head_glove(z, zg, self.labels, 1, want_grad=True)
-            e.encoder_backward(x)
             e.glove_backward()
+            e.encoder_backward(x)
         else:
             out, pred, _ = e.head(z, self.labels, 1, want_grad=True)
             e.encoder_backward(x)

@@ -234,9 +234,11 @@ class Model(nn.Module):
         if st is None or not st["want_grad"]:
             raise RuntimeError("backward without a training-mode forward")
         if not st["done"]:
-            self.engine.encoder_backward(st["x"])
+            # the glove-angle class encoder first: data-parallel runs sum everything but the conv stack's gradients behind
+            # an event that encoder_backward records (dist.GradAllReduce), and its gradients are in that bucket
             if self.class_encoder == "glove":
                 self.engine.glove_backward()
+            self.engine.encoder_backward(st["x"])
             st["done"] = True
 
     # -- fused step API ------------------------------------------------------------------------------
