@@ -52,3 +52,36 @@ def test_fc_gradients_are_final_at_the_event(dtype, dp):
         assert torch.equal(v, plain[k]), k                  # and the call computes what the plain one does
     # the conv stack is what is still being computed behind the event: it is the (small) front of the buffer
     assert split * 4 < 0.2 * 2 ** 20
+
+
+def test_glove_class_encoder_gradients_are_final_at_the_event():
+    """With the glove-angle class encoder the class encoder's gradients live in the same bucket; its
+    backward is enqueued first (models.py, bench.py), so they too are final when the event fires."""
+    from contrastiveprosthetics_amd.engine import Engine
+    groups = 300
+    n = groups * T
+    g = torch.Generator().manual_seed(21)
+    mu = torch.randn(T, 12, generator=g)
+    x = (mu[None] + torch.randn(groups, T, 12, generator=g)).reshape(n, 12).cuda()
+    glove = (torch.randn(T, 20, generator=g)[None] + 0.3 * torch.randn(groups, T, 20, generator=g)).cuda()
+    labels = torch.arange(T).repeat(groups).cuda()
+    e = Engine(adabn=False, dtype="bf16", dp_emg=0.0635, device="cuda", seed=5, class_encoder="glove")
+    e.init_parameters(7)
+    e.grads.flat.zero_()
+    split = e.grads.offsets["emg_net.linear.0.weight"][0]
+    ev = torch.cuda.Event()
+    ev.record()
+    e.fc_grads_ready = ev
+    side = torch.cuda.Stream()
+    z = e.encoder_forward(x, training=True)
+    zg = e.glove_forward(glove, training=True)
+    e.head_glove(z, zg, labels, 1, want_grad=True)
+    e.glove_backward()
+    e.encoder_backward(x)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        snap = e.grads.flat[split:].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(snap, e.grads.flat[split:])
+    moved = [k for k, v in e.grads.views.items() if k.startswith("glove_net.") and float(v.abs().sum()) > 0]
+    assert moved, "the class encoder's gradients were written"
