@@ -422,6 +422,7 @@ extern "C" int cp_encoder_forward(const cp_config* cfg, const cp_params* p, cons
     WS w;
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !z_out) return fail(CP_ERR_ARG, "cp_encoder_forward args");
+    if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
     if (cfg->dtype == CP_BF16)
         return encoder_forward_t<bf16_t>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
     return encoder_forward_t<float>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
@@ -1052,6 +1053,7 @@ extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, 
     WS w;
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !grads) return fail(CP_ERR_ARG, "cp_encoder_backward args");
+    if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
     if (cfg->dtype == CP_BF16)
         return encoder_backward_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
     return encoder_backward_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);

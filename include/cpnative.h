@@ -114,7 +114,8 @@ int cp_gather_groups(const float* table, int64_t table_rows, const int64_t* emg_
                      const int64_t* perm, int64_t B, int32_t V, float* x_out, void* stream);
 
 /* EMGNet.forward (code/models.py:319-342): conv_emg -> linear -> last.
- * x (n_windows,12) f32; z_out (n_windows,16) f32 in the same row order (the regroup of
+ * x (n_windows,12) f32, 16-byte aligned (a window's 12 values are read as three 16-byte loads; cp_gather_groups'
+ * output and any torch allocation are); z_out (n_windows,16) f32 in the same row order (the regroup of
  * models.py:337-341 is a pure index map applied by cp_head).  Saves what backward needs in ws. */
 int cp_encoder_forward(const cp_config* cfg, const cp_params* p, const cp_bn_buffers* bn,
                        const float* x, void* ws, size_t ws_bytes, float* z_out, void* stream);
