@@ -32,11 +32,15 @@ struct OptArgs {
     OptTensor t[CP_MAX_TENSORS];
 };
 
+// the tensor a chunk belongs to: last i with t[i].chunk0 <= chunk (chunk0 ascends; a binary search, six probes of the
+// kernel-argument table per block instead of a scan over all of it)
 __device__ __forceinline__ int opt_find_tensor(const OptArgs& a, int chunk) {
-    int ti = 0;
-    for (int i = 0; i < a.n_tensors; ++i)
-        if (chunk >= a.t[i].chunk0) ti = i;
-    return ti;
+    int lo = 0, hi = a.n_tensors - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.t[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
 __global__ __launch_bounds__(256) void l2_sumsq_kernel(OptArgs a) {
