@@ -876,6 +876,8 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
             nr = gb;
             pp = pre(nr, 512);
+            // (the bias gradient is consumed within this pass -- reduce_slabs' BatchNorm un-fold and
+            //  bn_bwd_sums_from_wgrad_kernel read it -- so these small launches cannot be batched at the end of the loop)
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[i]);
             CKL("bn_relu_bwd_kernel");
         }
