@@ -58,6 +58,7 @@ SYMBOLS = {
     "cp_last_error": (C.c_char_p, []),
     "cp_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_float]),
     "cp_gather_groups": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, C.c_int32, _fp, _fp]),
+    "cp_gather_oob_count": (C.c_int, [_fp, C.c_int32, _fp]),
     "cp_encoder_forward": (C.c_int, [_P(cp_config), _P(cp_params), _P(cp_bn_buffers), _fp, _fp, C.c_size_t, _fp, _fp]),
     "cp_head": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t,
                           _fp, _fp, _fp, _P(cp_params), _fp]),

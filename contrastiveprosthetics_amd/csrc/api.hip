@@ -242,6 +242,15 @@ extern "C" int cp_gather_groups(const float* table, int64_t table_rows, const in
     return 0;
 }
 
+extern "C" int cp_gather_oob_count(uint32_t* count_out, int32_t reset, void* stream) {
+    if (!count_out) return fail(CP_ERR_ARG, "cp_gather_oob_count args");
+    unsigned int* ctr = nullptr;
+    CK(hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(g_gather_oob)));
+    CK(hipMemcpyAsync(count_out, ctr, sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (reset) CK(hipMemsetAsync(ctr, 0, sizeof(uint32_t), (hipStream_t)stream));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // encoder forward
 // ---------------------------------------------------------------------------------------

@@ -14,6 +14,9 @@
 // code/load.py:256-273).  train: src row = emg_rand[t][perm[b]];  eval: 25 consecutive
 // rows of tensor[emg_rand[t][perm[b]]].  One thread per output float4 (3 per window).
 // ------------------------------------------------------------------------------------
+// g_gather_oob counts source rows that fell outside the table (a wrong emg_rand / V / table combination): such a row
+// is read from row 0 so the launch stays memory-safe, and the count is there for cp_gather_oob_count to report.
+__device__ unsigned int g_gather_oob;
 __global__ void gather_groups_kernel(const float* __restrict__ table, const int64_t* __restrict__ emg_rand,
                                      const int64_t* __restrict__ perm, float* __restrict__ out, int64_t B, int T,
                                      int V, int64_t D, int64_t table_rows) {
@@ -26,7 +29,10 @@ __global__ void gather_groups_kernel(const float* __restrict__ table, const int6
         const int t = (int)(bt % T);
         const int64_t b = bt / T;
         int64_t src = emg_rand[(int64_t)t * D + perm[b]] * V + v;      // row of the (rows,12) table
-        if (src < 0 || src >= table_rows) src = 0;
+        if (src < 0 || src >= table_rows) {
+            if (q == 0) atomicAdd(&g_gather_oob, 1u);
+            src = 0;
+        }
         *(float4*)(out + win * 12 + q * 4) = *(const float4*)(table + src * 12 + q * 4);
     }
 }

@@ -117,6 +117,20 @@ class GradAllReduce:
         return self.flat
 
 
+def barrier():
+    """All ranks meet here (no-op for one process): e.g. between rank 0 writing a checkpoint and everybody reading it."""
+    if world_size() > 1:
+        td.barrier()
+
+
+def broadcast_buffers_(tensors, src: int = 0):
+    """Rank src's BatchNorm running statistics to every rank before an evaluation, as DDP's broadcast_buffers does
+    (training keeps them rank-local: each rank updates them from its own shard)."""
+    if world_size() > 1:
+        for t in tensors:
+            td.broadcast(t, src)
+
+
 def broadcast_(flat: torch.Tensor, src: int = 0) -> torch.Tensor:
     if world_size() > 1:
         td.broadcast(flat, src)

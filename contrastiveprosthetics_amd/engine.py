@@ -126,6 +126,16 @@ def gather_groups(table: torch.Tensor, emg_rand: torch.Tensor, perm: torch.Tenso
     return out
 
 
+def gather_oob_count(device="cuda", reset: bool = True) -> int:
+    """Source rows cp_gather_groups found outside the table since the last reset (0 in a healthy run); one host sync."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    out = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.cp_gather_oob_count(out.data_ptr(), 1 if reset else 0, torch.cuda.current_stream(dev).cuda_stream),
+               "cp_gather_oob_count")
+    return int(out.item()) & 0xFFFFFFFF
+
+
 def subset_vote(logits: torch.Tensor, labels: torch.Tensor, B: int, V: int, masks: torch.Tensor, want_pred: bool = False):
     """cp_subset_vote: logits (B*V,41,41) f32, labels (41) int64, masks (n,41) uint8 ->
     correct (n,V) int64 [, y_pred (n,B,41) int32]  (README.md:11-19, code/models.py:146-163)."""
@@ -246,9 +256,13 @@ class Engine:
         return c
 
     def workspace(self, n_windows: int) -> torch.Tensor:
+        """Scratch for up to n_windows rows; grows on demand.  A captured step graph has the address of the buffer it
+        was captured with baked into every kernel node: GraphStep keeps its own reference to that tensor, so growing the
+        engine's workspace later (an evaluation batch of 25x the rows) allocates a second buffer and leaves the
+        graph's alone instead of handing it back to the caching allocator."""
         if self._ws is None or n_windows > self._ws_windows:
             nbytes = self.lib.cp_workspace_bytes(n_windows, self.dtype, self.dp_emg)
-            self._ws = None
+            self._ws = None                                   # (frees the old block first unless a GraphStep holds it)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws_windows = n_windows
         return self._ws
@@ -503,12 +517,20 @@ class GraphStep:
         self.perm = torch.zeros(self.B, dtype=torch.int64, device=dev)
         self.labels = torch.arange(CP_TASKS, device=dev).repeat(self.B)
         self.state = torch.zeros(8, dtype=torch.float32, device=dev)
-        self._host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        # per-step values travel through a RING of pinned slots: the host runs ahead of the GPU inside an epoch (no sync
+        # per step), so one reused slot would be rewritten while earlier async copies from it are still queued and
+        # those steps would read a later step's bias corrections and dropout salt.  A slot is reused only after the
+        # event recorded behind its last copy has completed.
+        self._host = torch.zeros(self.RING, 8, dtype=torch.float32).pin_memory()
+        self._host_ev = [None] * self.RING
+        self._slot = 0
         self.glove = glove                                  # callable perm -> (B,41,20) tensor, or None
         self.lr_scale = [1.0, 1.0]
         # the sampler table is re-drawn by TaskWrapper.reset() every epoch: the graph reads a copy at a fixed address
         self.table, self.emg_rand = table, emg_rand.clone()
-        engine.workspace(self.B * CP_TASKS)
+        # the graph's own reference to the buffers whose addresses it bakes (see Engine.workspace)
+        self._ws = engine.workspace(self.B * CP_TASKS)
+        self._gws = None
         self._push()
         # the warm-up below is a real step on real state, and capturing runs the host side of every call once more:
         # snapshot what they touch and put it back
@@ -527,6 +549,7 @@ class GraphStep:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = self._body(grad_scale)
+            self._gws = engine._gws                         # glove workspace captured with the graph, if any
         finally:
             engine._graph_state = None
             engine.values.flat.copy_(keep[0]); engine.exp_avg.copy_(keep[1]); engine.exp_avg_sq.copy_(keep[2])
@@ -549,10 +572,16 @@ class GraphStep:
         e.adam_step_graph(self.params, grad_scale)
         return out
 
+    RING = 64
+
     def _push(self):
         e = self.e
         t = e.adam_steps + 1
-        h = self._host
+        i = self._slot
+        self._slot = (i + 1) % self.RING
+        if self._host_ev[i] is not None:
+            self._host_ev[i].synchronize()                  # normally long done: 64 steps ago
+        h = self._host[i]
         salt = (e.step_count + 1) * 0x9E3779B1 & 0xFFFFFFFF
         h.view(torch.int32)[0] = salt - (1 << 32) if salt >= (1 << 31) else salt
         b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))   # the betas as the C side holds them (float)
@@ -561,13 +590,18 @@ class GraphStep:
         h[3] = float(self.params.get("lr_emg", 0.0)) * self.lr_scale[0]
         h[4] = float(self.params.get("lr_glove", 0.0)) * self.lr_scale[1]
         self.state.copy_(h, non_blocking=True)
+        if self._host_ev[i] is None:
+            self._host_ev[i] = torch.cuda.Event()
+        self._host_ev[i].record()
 
     def set_sampler(self, emg_rand: torch.Tensor):
         """TaskWrapper.reset() drew a new (41, D) table: refresh the graph's copy (same shape)."""
         self.emg_rand.copy_(emg_rand)
 
     def step(self, perm: torch.Tensor) -> torch.Tensor:
-        """perm: the B item indices of this batch (device int64).  Returns the device tensor (loss, #correct)."""
+        """perm: the B item indices of this batch (DEVICE int64: a device-to-device copy is stream-ordered, a host
+        tensor here would race with earlier replays).  Returns the device tensor (loss, #correct)."""
+        assert perm.is_cuda, "GraphStep.step takes the batch indices as a device tensor"
         self.perm.copy_(perm, non_blocking=True)
         self._push()
         self.graph.replay()

@@ -105,10 +105,12 @@ class _L2Fn(torch.autograd.Function):
 
 class Model(nn.Module):
     def __init__(self, params, adabn=True, train_model=True, prediction=False, glove=False, device="cuda",
-                 dtype: str = "f32", seed: int = 42, class_encoder: str = "onehot"):
+                 dtype: str = "f32", seed: int = 42, class_encoder: str = "onehot", dropout_seed: int = None):
         """class_encoder="glove" (additive): class embeddings come from the glove-angle rows that
         TaskWrapper already delivers, through the layers GLOVENet keeps as comments (code/models.py:386-391, 461),
-        instead of the one-hot table.  (The reference's own `glove` flag belongs to its --prediction classifier.)"""
+        instead of the one-hot table.  (The reference's own `glove` flag belongs to its --prediction classifier.)
+        seed initialises the parameters; dropout_seed (default: seed) keys the dropout stream -- data-parallel ranks
+        pass seed + rank there so that their shards do not share one mask (parameters are broadcast anyway)."""
         super().__init__()
         if prediction or glove:
             raise NotImplementedError("only the contrastive mode (prediction=False, glove=False) is accelerated; "
@@ -121,7 +123,8 @@ class Model(nn.Module):
         self.device = torch.device(device)
         self.class_encoder = class_encoder
         self.engine = Engine(adabn=adabn, dtype=dtype, dp_emg=float(params.get("dp_emg", 0.0)), device=device,
-                             d_e=int(params["d_e"]), seed=seed, class_encoder=class_encoder)
+                             d_e=int(params["d_e"]), seed=seed if dropout_seed is None else dropout_seed,
+                             class_encoder=class_encoder)
         self.engine.init_parameters(seed)
         self.emg_net = EMGNet()
         self.glove_net = GLOVENet()

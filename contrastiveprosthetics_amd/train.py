@@ -58,15 +58,37 @@ def validate(model, dataset):
     return _evaluate(model, dataset, args.batch_size)
 
 
+def lr_scales(epoch: int, annealing: bool, final_epochs: int):
+    """The reference's schedulers (code/train.py:75-80, stepped once per epoch at :112-113) as closed forms, applied as
+    multipliers (emg, glove) to the fused optimiser's learning rates.  annealing: CosineAnnealingLR(T_max=final_epochs,
+    eta_min=0) on both optimisers.  Otherwise the reference builds StepLR(step_size=5, gamma=.2) twice and BOTH wrap
+    optimizer_glove (a quirk kept here): the glove rate falls by .2**2 every 5 epochs, the emg rate never moves.
+    tests/test_cabi_and_host.py holds these to torch.optim.lr_scheduler."""
+    if annealing:
+        s = 0.5 * (1 + np.cos(np.pi * epoch / final_epochs))
+        return [s, s]
+    return [1.0, 0.2 ** (2 * (epoch // 5))]
+
+
+def _sync_bn_buffers(model, world):
+    """Before an evaluation under data parallelism: every rank takes rank 0's running statistics (training leaves them
+    rank-local, so without this each rank would evaluate with different buffers)."""
+    if world > 1 and model.engine.running:
+        cpdist.broadcast_buffers_([v for k, v in model.engine.running.items() if v.dtype.is_floating_point])
+
+
 def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints/model", annealing=False, load=None,
                verbose=False, solo=False):
     """code/train.py:65-138.  solo: this process trains the model alone even inside a multi-process job (packed sweep)."""
+    world, rank = (1, 0) if solo else (cpdist.world_size(), cpdist.rank())
+    # parameters start identical on every rank (seed 42, and rank 0's are broadcast below); the dropout stream is keyed
+    # per rank so that the shards of one global batch do not share a mask
     model = Model(params=params, train_model=True, adabn=args.no_adabn, prediction=args.prediction, glove=args.glove,
-                  device="cuda", dtype=args.dtype, class_encoder=getattr(args, "class_encoder", "onehot")).to(torch.float32)
+                  device="cuda", dtype=args.dtype, class_encoder=getattr(args, "class_encoder", "onehot"),
+                  dropout_seed=42 + rank).to(torch.float32)
     if load is not None:
         print("Loading model")
         model.load_state_dict(torch.load(load + ".pt", weights_only=True))
-    world, rank = (1, 0) if solo else (cpdist.world_size(), cpdist.rank())
     if world > 1:
         cpdist.broadcast_(model.engine.values.flat)
         reduce_grads = cpdist.GradAllReduce(model.engine)     # two buckets, the large one beside the conv backward
@@ -81,12 +103,7 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
     graph_step = None
     print("Training...")
     for e in range(epochs):
-        # schedulers of code/train.py:75-80,112-113 as closed forms applied to the fused optimiser's lr
-        if annealing:                      # CosineAnnealingLR(T_max=final_epochs, eta_min=0) on both
-            s = 0.5 * (1 + np.cos(np.pi * e / args.final_epochs))
-            model.lr_scale = [s, s]
-        else:                              # reference quirk: BOTH StepLR(5, .2) wrap optimizer_glove
-            model.lr_scale = [1.0, 0.2 ** (2 * (e // 5))]
+        model.lr_scale = lr_scales(e, annealing, args.final_epochs)      # schedulers of code/train.py:75-80,112-113
         loss_train = []
         t0 = time.time()
         nwin = 0
@@ -121,6 +138,7 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
         loss_train = float(torch.cat([l.reshape(1) for l in loss_train]).mean().item())
         dt = time.time() - t0
         if verbose:
+            _sync_bn_buffers(model, world)
             loss_val, acc_val = validate(model, dataset)
             final_val_acc = (loss_val, acc_val)
             val_losses[e] = loss_val
@@ -130,9 +148,12 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
             print("Checkpointing model...")
             os.makedirs(os.path.dirname(checkpoint_dir) or ".", exist_ok=True)
             torch.save(model.state_dict(), checkpoint_dir + ".pt")
+        if checkpoint and verbose and world > 1:
+            cpdist.barrier()              # rank 0's file is complete before any rank goes on (and, in the end, loads it)
         model.set_train()
         dataset.set_train()
     if not verbose:
+        _sync_bn_buffers(model, world)
         loss_val, acc_val = validate(model, dataset)
         print("Epoch %d. Train loss: %.4f\tVal loss: %.4f\tVal acc: %.6f\tTrain acc: %.4f" %
               (epochs - 1, loss_train, loss_val, acc_val, acc_train))
@@ -219,8 +240,12 @@ def main(a):
                                    load=checkpoint_dir if args.load_model else None, solo=solo_final)
     print("Final validation model statistics")
     print(final_vals)
+    if not solo_final:
+        cpdist.barrier()                  # nobody reads the checkpoint while rank 0 may still be writing it
     if os.path.exists(checkpoint_dir + ".pt"):
         model.load_state_dict(torch.load(checkpoint_dir + ".pt", weights_only=True))
+    elif not solo_final:
+        _sync_bn_buffers(model, cpdist.world_size())
     if args.test:
         final_stats = test(model, dataset23)
         print("loss,\t\t\tcorrect")

@@ -112,6 +112,11 @@ size_t cp_workspace_bytes(int64_t max_windows, int32_t dtype, float dp_emg);
  * x_out: (B,41,V,12) f32 -- the collated EMG tensor in encoder row order. */
 int cp_gather_groups(const float* table, int64_t table_rows, const int64_t* emg_rand, int64_t D,
                      const int64_t* perm, int64_t B, int32_t V, float* x_out, void* stream);
+/* cp_gather_groups reads a source row outside [0, table_rows) from row 0 (the reference would raise an IndexError at
+ * code/load.py:262-266) and counts it; this copies the running count of such rows since the last reset into the DEVICE
+ * word count_out (stream-ordered) and, with reset != 0, zeroes it afterwards.  Non-zero = emg_rand, V and the table
+ * do not belong together. */
+int cp_gather_oob_count(uint32_t* count_out, int32_t reset, void* stream);
 
 /* EMGNet.forward (code/models.py:319-342): conv_emg -> linear -> last.
  * x (n_windows,12) f32, 16-byte aligned (a window's 12 values are read as three 16-byte loads; cp_gather_groups'

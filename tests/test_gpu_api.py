@@ -273,3 +273,23 @@ def test_misaligned_input_is_rejected_not_faulted():
     x = buf[1:].view(41, 12)                       # 4 bytes off a 16-byte boundary
     with _pytest.raises(CpNativeError):
         e.encoder_forward(x, training=True)
+
+
+def test_gather_counts_rows_outside_the_table():
+    """A sampler table that does not belong to the resident tensor (indices past its end) must not pass silently:
+    cp_gather_groups stays memory-safe (reads row 0) and cp_gather_oob_count reports how many rows were affected."""
+    from contrastiveprosthetics_amd import engine as E
+    D = 50
+    table = torch.randn(T * D, 12, device="cuda")
+    emg_rand = (torch.rand(T, D).argsort(-1) + torch.arange(T).reshape(T, 1) * D).cuda()
+    perm = torch.arange(8).cuda()
+    E.gather_oob_count(reset=True)
+    x = E.gather_groups(table, emg_rand, perm, 1)
+    assert E.gather_oob_count(reset=True) == 0
+    assert torch.equal(x.reshape(8, T, 12), table[emg_rand[:, :8].t().reshape(-1)].reshape(8, T, 12))
+    bad = emg_rand.clone()
+    bad[3, 2] = T * D + 5                                    # one (class, item) cell points past the table
+    bad[7, 0] = -1
+    E.gather_groups(table, bad, perm, 1)
+    assert E.gather_oob_count(reset=True) == 2
+    assert E.gather_oob_count(reset=False) == 0
