@@ -91,6 +91,7 @@ SYMBOLS = {
     "cp_profile_resume": (C.c_int, []),
     "cp_profile_summary": (C.c_int, [C.c_int32, _P(C.c_double), _P(C.c_int64)]),
     "cp_debug_activation": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, C.c_int32, _fp, _fp]),
+    "cp_debug_set_grad_tap": (C.c_int, [_fp, C.c_size_t]),
     "cp_debug_bn_stats": (C.c_int, [_P(cp_config), _fp, C.c_size_t, C.c_int32, _fp, _fp]),
     "cp_debug_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp,
                                 C.c_int32, _fp]),

@@ -563,6 +563,24 @@ extern "C" int cp_emg_normalize(float* seg, int64_t n_rows, const float* mean_st
 // ---------------------------------------------------------------------------------------
 // encoder backward
 // ---------------------------------------------------------------------------------------
+// test aid (cp_debug_set_grad_tap): device buffer of 9 slots x n_windows x 768 elements of the compute dtype that receives a
+// copy of every intermediate gradient of the backward pass, so that each backward kernel can be checked on its own
+// inputs at full batch size (tests/test_gpu_fullsize.py).  nullptr (the default) = no copies.
+static unsigned char* g_grad_tap = nullptr;
+static size_t g_grad_tap_bytes = 0;
+extern "C" int cp_debug_set_grad_tap(void* tap, size_t bytes) {
+    g_grad_tap = (unsigned char*)tap;
+    g_grad_tap_bytes = tap ? bytes : 0;
+    return 0;
+}
+static int tap_gradient(int slot, const void* src, int64_t n_windows, int width, size_t es, hipStream_t st) {
+    if (!g_grad_tap) return 0;
+    const size_t slot_bytes = (size_t)n_windows * 768 * es, bytes = (size_t)n_windows * width * es;
+    if ((size_t)(slot + 1) * slot_bytes > g_grad_tap_bytes) return fail(CP_ERR_ARG, "gradient tap buffer too small");
+    CK(hipMemcpyAsync(g_grad_tap + slot * slot_bytes, src, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
 static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t* rows_per_split);
 
 // ---------------------------------------------------------------------------------------
@@ -890,6 +908,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[i]);
             CKL("bn_relu_bwd_kernel");
         }
+        if (int e = tap_gradient(L, cur, N, 512, sizeof(T), st)) return e;        // dL/d(pre-activation of layer L)
         const bool in_drop = drop && Lp >= 5;
         const T* Y = in_drop ? (const T*)(base + w.u[Lp - 5]) : act(Lp);
         const float* s = in_drop ? nullptr : stats(Lp) + 2 * kLayerC[Lp];
@@ -1008,6 +1027,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
             CKL("bn_relu_bwd_kernel(conv2)");
         }
+        if (int e = tap_gradient(1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
         ConvArgs ca{};
         ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0); ca.gin = cur; ca.n_windows = N;
         {
@@ -1039,6 +1059,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             CKL("conv2_strip_kernel<dgrad>");
         }
     }
+    if (int e = tap_gradient(0, nxt, N, 768, sizeof(T), st)) return e;             // dL/d(BN1 output), [w][c]
     // ---- conv1 -----------------------------------------------------------------------------
     {
         ProfScope ps(CP_K_CONV1_BWD, st);

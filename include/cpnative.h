@@ -287,6 +287,12 @@ int cp_debug_gemm(int32_t dtype, int32_t kind, int64_t M, int32_t K, int32_t F, 
                   const void* W, void* C, const float* bias, const void* R, float* partials,
                   int32_t dbg, void* stream);
 
+/* test aid: while `tap` is non-NULL, cp_encoder_backward copies every intermediate gradient into it (stream-ordered):
+ * 9 slots of n_windows x 768 elements of the compute dtype; slot L = 2..8: dL/d(pre-activation of fc layer L-1), i.e. after
+ * BatchNorm + ReLU backward, n_windows x 512; slot 1: dL/d(conv2 pre-activation), slot 0: dL/d(BN1 output), both
+ * n_windows x [12 positions][64 channels].  bytes = size of the buffer.  NULL switches the copies off (the default). */
+int cp_debug_set_grad_tap(void* tap, size_t bytes);
+
 /* BN statistics of `layer` as computed by the last forward: out[4][C] = mean, invstd, scale, shift */
 int cp_debug_bn_stats(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer, float* out,
                       void* stream);
