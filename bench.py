@@ -77,14 +77,12 @@ def gemm_model(kind: str, n: int, es: int, dropout: bool):
 
 def cpu_baseline(seconds: float, threads: int):
     """The reference step on host cores: oracle (pure torch CPU restatement: per-item gather, 3x3
-    Conv2d, per-group CE loop, separate norms, 2 x Adam), B=64 groups (its best CPU batch)."""
+    Conv2d, per-group CE loop, separate norms, 2 x Adam).  Headline = B=64 groups (its best CPU batch, SURVEY 6);
+    `b8` = BASELINE config 1's own batch size (8 groups), about a third of the sample time.  The port's step time is
+    held to the imported reference's in the build container by tools/time_port_vs_reference.py
+    (profiles/r02_port_vs_reference.json: within 10 % at both sizes)."""
     from oracle import ref_cpu as oc
     torch.set_num_threads(threads)
-    B = 64
-    sd = oc.init_state_dict(0, 16, adabn=False)
-    m = oc.OracleModel(sd, BEST, adabn=False, requires_grad=True)
-    m.set_train()
-    opts = m.make_optimizers()
     EMG, GLOVE = oc.synthetic_resident(1234, glove_d=64)
     db = oc.OracleDB23(EMG, GLOVE)
     db.set_mode("train")
@@ -92,20 +90,32 @@ def cpu_baseline(seconds: float, threads: int):
     emg_rand = oc.make_rand_table(torch.rand(db.TASKS, db.D))
     glove_rand = oc.make_rand_table(torch.rand(db.TASKS, db.D_g))
 
-    def one(i):
-        idx = torch.randperm(db.D)[:B]
-        e, g, lab = oc.collate(db, emg_rand, glove_rand, idx)
-        m.train_step(e, g, lab.reshape(-1), opts)
+    def run(B, secs):
+        sd = oc.init_state_dict(0, 16, adabn=False)
+        m = oc.OracleModel(sd, BEST, adabn=False, requires_grad=True)
+        m.set_train()
+        opts = m.make_optimizers()
 
-    one(0)
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < seconds:
-        one(n)
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=n * B * T / dt, unit="windows/s", cores=threads, kind="port",
-                sample=f"{n} steps of B={B} groups ({B * T} windows) in {dt:.1f} s, fp32, oracle/ref_cpu.py")
+        def one():
+            idx = torch.randperm(db.D)[:B]
+            e, g, lab = oc.collate(db, emg_rand, glove_rand, idx)
+            m.train_step(e, g, lab.reshape(-1), opts)
+
+        one()
+        one()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < secs:
+            one()
+            n += 1
+        dt = time.perf_counter() - t0
+        return dict(value=n * B * T / dt, unit="windows/s",
+                    sample=f"{n} steps of B={B} groups ({B * T} windows) in {dt:.1f} s, fp32, oracle/ref_cpu.py")
+
+    big = run(64, seconds * 2.0 / 3.0)
+    small = run(8, seconds / 3.0)
+    return dict(value=big["value"], unit="windows/s", cores=threads, kind="port", sample=big["sample"],
+                b8=dict(small, cores=threads, note="BASELINE config 1 batch size (train.py --batch_size 8 --no_adabn)"))
 
 
 def main():
@@ -218,8 +228,12 @@ def main():
         step(i)
     gemm_kinds = ["fc_fwd", "fc_dgrad", "fc_dgrad_bn", "fc_dgrad_stats", "fc_wgrad"]
     eng.profile_enable(gemm_kinds, max_records=64 * (args.steps + 1))
+    # one event per step boundary on the launch stream: min / median / max step time inside the timed region (the same
+    # launch moves by +-10 % with the clock state of the box; the spread says how steady this run was)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         # the live per-kernel timing brackets each fc GEMM launch with two HIP events, and every event record idles
         # the queue for ~5 us (58 of them per step = 6 % of it): sample every --profile_every-th step
@@ -228,8 +242,10 @@ def main():
         else:
             eng.profile_disable()
         step(args.warmup + i)
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     profiled_steps = len(range(0, args.steps, args.profile_every))
     eng.profile_disable()
     prof = eng.profile_summary()
@@ -296,7 +312,9 @@ def main():
                                global_batch_groups=world * B, windows_per_step=world * N,
                                parallelism=f"dp{world}" + (" + z all-gather + flat-gradient all-reduce (RCCL)" if world > 1 else ""),
                                tile_schedule="dynamic" if eng.lib.cp_get_tile_schedule() else "static"),
-                   loss=loss, train_acc=correct / N, roofline=roof)
+                   loss=loss, train_acc=correct / N, roofline=roof,
+                   steps_spread=dict(min_ms=step_ms[0], median_ms=step_ms[len(step_ms) // 2], max_ms=step_ms[-1],
+                                     note="per-step HIP events on the launch stream, rank 0"))
         if rehearse:
             rec["rehearsal"] = f"ranks share one GPU over {rehearse}: control-flow check only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:

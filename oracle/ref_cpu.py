@@ -252,6 +252,8 @@ class OracleModel:
         sd = self.sd
 
         def relu(y, layer):
+            if taps is not None:
+                taps[f"pre{layer}"] = y                      # pre-activation (test aid: how close to zero a flipped ReLU was)
             if relu_masks is not None and layer in relu_masks:
                 return y * relu_masks[layer].to(y.dtype)
             return F.relu(y)

@@ -113,7 +113,19 @@ def test_backward_f32(adabn, B):
     m0, _, _ = oracle_grads(sd, adabn, EMG, label)
     taps = {}
     oc.OracleModel(sd, BEST, adabn=adabn).forward(EMG, torch.zeros(B, T, 20), label, taps)
-    flips = sum(int((masks[l] != (taps[f"r{l}"] > 0)).sum()) for l in range(9))
+    flips, worst_flip = 0, 0.0
+    for l in range(9):
+        flipped = masks[l] != (taps[f"r{l}"] > 0)
+        nf = int(flipped.sum())
+        flips += nf
+        if nf:
+            # a disagreement about the sign is legitimate only where the oracle's own pre-activation is zero to f32
+            # rounding: a K-term f32 dot product carries ~sqrt(K) * 2^-24 ~ 2e-6 of its scale
+            pre = taps[f"pre{l}"].detach()
+            ratio = float(pre[flipped].abs().max()) / float(pre.abs().max())
+            worst_flip = max(worst_flip, ratio)
+            assert ratio <= 1e-5, f"layer {l}: a flipped ReLU site has |pre-activation| = {ratio:.2e} of the layer's max"
+    print(f"ReLU sign disagreements: {flips}, largest |oracle pre-activation| / max at such a site: {worst_flip:.2e}")
     assert flips <= 8, f"{flips} ReLU sign disagreements is more than rounding explains"
     m, logits_ref, loss_ref = oracle_grads(sd, adabn, EMG, label, relu_masks=masks)
     np.testing.assert_allclose(logits.cpu().numpy(), logits_ref.numpy(), atol=2e-5, rtol=0)
@@ -195,6 +207,9 @@ def test_bf16_path(adabn):
     # 8 significant bits and each BatchNorm re-amplifies the relative error by rms/std of the post-ReLU
     # values, measured ~0.2 %/layer -> 2 % on fc7's output, 6e-3 rms / 4e-2 max on the cosine logits.
     rms = float((logits.cpu() - logits_ref).pow(2).mean().sqrt())
+    print(f"SURVEY 8c bf16 bar (max |dlogit| <= 2e-2, argmax agreement >= 99 %) at random init: "
+          f"{'PASS' if err <= 2e-2 and agree >= 0.99 else 'FAIL'} (reported, not gated: top-2 margins are ~1e-3 here; "
+          f"test_bf16_trained_model_agreement is the trained-model case)")
     assert err < 6e-2 and rms < 1.2e-2
     assert agree > 0.93
     assert out[0].item() == pytest.approx(loss_ref.item(), rel=2e-3)
@@ -209,6 +224,48 @@ def test_bf16_path(adabn):
     # the gradient noise grows towards the input (18 bf16 tensors deep at conv1)
     assert min(cos.values()) > 0.94, min(cos.items(), key=lambda kv: kv[1])
     assert cos["emg_net.last.0.weight"] > 0.995 and cos["glove_net.easy.0.weight"] > 0.995
+
+
+def test_bf16_trained_model_agreement():
+    """The bf16 bar of SURVEY 8c on a TRAINED model: 60 fused optimisation steps in f32 on class-dependent
+    synthetic windows (the loss falls, top-2 margins open up), then the same weights and a fresh batch through the bf16
+    HIP path and the f32 CPU oracle."""
+    adabn, B = False, 16
+    sd = oc.init_state_dict(31, 16, adabn)
+    e = make_engine(sd, adabn, "f32")
+    g = torch.Generator().manual_seed(12)
+    mu = torch.randn(T, 12, generator=g)
+    label = torch.arange(T).repeat(64)
+    first = last = None
+    for s in range(60):
+        EMG = (mu[None] + 0.7 * torch.randn(64, T, 12, generator=g)).reshape(64, T, 1, 1, 12)
+        out, _, _ = run_step(e, EMG, label)
+        e.adam_step(BEST)
+        first = out[0].item() if first is None else first
+        last = out[0].item()
+    assert last < first - 0.3, (first, last)
+    trained = {k: v.detach().cpu().clone() for k, v in e.values.views.items()}
+    for k, v in e.running_state().items():
+        trained[k] = v.detach().cpu().clone()
+    trained["logit_scale"] = sd["logit_scale"]
+    trained = {k: trained[k] for k in sd}                           # reference key order
+    EMG = (mu[None] + 0.7 * torch.randn(B, T, 12, generator=g)).reshape(B, T, 1, 1, 12)
+    label = torch.arange(T).repeat(B)
+    m = oc.OracleModel(trained, BEST, adabn=adabn)
+    logits_ref = m.forward(EMG, torch.zeros(B, T, 20), label)
+    eb = make_engine(trained, adabn, "bf16")
+    z = eb.encoder_forward(EMG.reshape(-1, 12).cuda(), training=True)
+    out, pred, logits = eb.head(z, label.cuda(), 1, want_grad=False, want_logits=True)
+    err = float((logits.cpu() - logits_ref).abs().max())
+    rms = float((logits.cpu() - logits_ref).pow(2).mean().sqrt())
+    agree = float((pred.cpu() == logits_ref.argmax(-1)).float().mean())
+    acc = float((logits_ref.argmax(-1) == torch.arange(T)).float().mean())
+    top2 = logits_ref.topk(2, -1).values
+    print(f"trained model (loss {first:.3f} -> {last:.3f}, oracle acc {acc:.3f}): bf16 max |dlogit| {err:.3e}, rms {rms:.3e}, "
+          f"argmax agreement {agree:.4f}, median top-2 margin {float((top2[..., 0] - top2[..., 1]).median()):.2e}; "
+          f"SURVEY 8c bar: {'PASS' if err <= 2e-2 and agree >= 0.99 else 'FAIL'}")
+    assert err < 6e-2 and rms < 1.2e-2
+    assert agree >= 0.97
 
 
 def test_dropout_replay_f32():
