@@ -40,7 +40,6 @@ struct GemmNTArgs {
     const uint32_t* dp_salt;   // optional device word XOR-ed into dp_key (graph replay: the per-step part of the key)
     float dp_inv_keep;
     int* sched;          // persistent kernel: its stream's tile counters (per XCD, and blocks finished; 32 ints apart); set by the launcher
-    int64_t rpw;         // persistent kernel, static schedule: rows per row worker (a multiple of 32); set by the launcher
 };
 
 template <typename T, int BM, int BN, int ALOAD, int EPI>

@@ -17,12 +17,8 @@
 // its second read is an L2 hit.  The bias / BatchNorm coefficients of every column tile sit in LDS; the
 // BatchNorm column sums leave as ONE partial row per SAMPLE TILE (not per block), so the sums downstream add
 // up in the same order whichever block ran which tile: results do not depend on the schedule.
-// Static: the rows are cut into 8 * J / tiles_f contiguous ranges of rpw rows (a multiple of 32), one per ROW WORKER = the
-// tiles_f blocks of one XCD that share a range (one column tile each, so the range's A rows are fetched from HBM once per
-// XCD); a worker walks its range in 256-row tiles, the last one ragged; a block carries the sums in registers and writes one
-// partial row.  Round 1 dealt whole 256-row tiles out instead: 656 sample tiles x 2 column tiles on 256 CUs = 5.125 rounds,
-// paid as 6 with 7/8 of the chip idle in the last one.  With ranges every CU gets 1,312 rows = 5 tiles + 32 rows, and the
-// ragged tile's waves without a live row (all of sample half 1 when at most 128 rows are left) skip their MFMAs.  Alone on the GPU that is 2-3 % faster (147 / 182 / 174 us for the
+// Static: block j of an XCD has a fixed column tile and every (J/tiles_f)-th sample tile, carries the sums in
+// registers and writes one partial row per block.  Alone on the GPU that is 2-3 % faster (147 / 182 / 174 us for the
 // three fc launches against 150 / 187 / 178, tools/ab_sched.sh), but with 8-32 CUs held by another stream's kernel
 // -- RCCL at N > 1, a neighbour process in a packed hyper-parameter sweep -- the blocks that start late hold the
 // whole launch back: 201-210 us against 150, where the dynamic form stays at 148-149 (tools/contention_bench.py).
@@ -39,6 +35,12 @@
 // 128 accumulator registers live the fetched tile and the coefficients did not fit: 53-63 spilled VGPRs,
 // +160..220 us per launch against the 94 us of the separate pass it replaced (which already streams at
 // 5.5 TB/s).
+//
+// Also measured (round 2): contiguous row ranges per block pair instead of whole tiles dealt round-robin -- every CU then
+// gets 1,312 rows = 5 tiles + a 32-row ragged tile whose dead waves skip their MFMAs, instead of 5.125 rounds "paid as 6".
+// A/B in alternating bench runs on one box: forward 154.5 vs 148.0 us, BN-mode data gradient 178.5 vs 181.3 us, step 4.50
+// vs 4.46 ms (median).  The sixth round was never a full round: its 32 tiles run on an otherwise idle chip (no contention for
+// L2, HBM and the power budget) in ~0.6 of a tile time, about what 256 ragged tiles with their full W fills cost.
 //
 // Also measured: F = 768 (fc1's data gradient: 3 column tiles, so the static form runs 30 blocks per XCD and 9 rounds)
 // through the per-tile code path with round-robin items on all 32 blocks (8 rounds): that launch 19 us faster (-8 %),
@@ -64,7 +66,6 @@
 // with a lone wave per SIMD nothing covers its LDS and barrier latencies, and hipcc's schedule does not either.
 #pragma once
 #include <mutex>
-#include <type_traits>
 #include "gemm_nt256.cuh"
 
 #define NT256P_MAX_TILES_F 3      // F <= 768: the encoder's widest data gradient
@@ -291,20 +292,10 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     const int xcd = blockIdx.x & 7;
     // work items of this XCD, handed out by its counter: item -> sample tile (item / tiles_f) * 8 + xcd, column tile
     // item % tiles_f, so the column tiles of one sample tile run at about the same time behind the same L2
+    const int items = xcd < tiles_m ? (int)((tiles_m - xcd + 7) / 8) * tiles_f : 0;
     int* ctr = a.sched + xcd * 32;                       // a 128-byte line per counter
     const int J = gridDim.x >> 3;
     const int ws = wave >> 2, wf = wave & 3;
-    // !DYN: this block's row worker and its range [w_begin, m_end); items = its 256-row tiles, walked in order
-    const int wk = (int)(blockIdx.x >> 3) / tiles_f * 8 + xcd;
-    const int64_t w_begin = DYN ? 0 : (int64_t)wk * a.rpw;
-    const int64_t m_end = DYN ? a.M : (w_begin + a.rpw < a.M ? w_begin + a.rpw : a.M);
-    const int items = DYN ? (xcd < tiles_m ? (int)((tiles_m - xcd + 7) / 8) * tiles_f : 0)
-                          : (w_begin < a.M ? (int)((m_end - w_begin + BM - 1) / BM) : 0);
-    auto tile_row0 = [&](int item) -> int64_t {
-        return DYN ? ((int64_t)(item / tiles_f) * 8 + xcd) * BM : w_begin + (int64_t)item * BM;
-    };
-    GemmNTArgs am = a;                                   // the epilogues mask rows against am.M = the end of this block's range
-    am.M = m_end;
 
     const T* __restrict__ Ag = (const T*)a.A;
     const T* __restrict__ Wg = (const T*)a.W;
@@ -321,13 +312,13 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
         }
     };
     auto set_src = [&](int item) {
-        const int64_t row0 = tile_row0(item);
+        const int64_t tm = (int64_t)(item / tiles_f) * 8 + xcd;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = (wave + 8 * i) * 8 + lrow;
             const int lch = pch ^ ((row >> 1) & 7);
-            int64_t m = row0 + row;
-            if (m >= m_end) m = m_end - 1;                           // clamp: such rows are never stored
+            int64_t m = tm * BM + row;
+            if (m >= a.M) m = a.M - 1;                               // clamp: such rows are never stored
             asrc[i] = Ag + m * a.lda + lch * EPC;
         }
         if constexpr (DYN) set_wsrc(item % tiles_f);
@@ -361,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
     __syncthreads();
     // the block's second item is drawn only now, behind every other block's first: neighbouring items -- the column
     // tiles of one sample tile -- go to different CUs at the same time and share the tile's rows in L2
-    int cur = DYN ? __builtin_amdgcn_readfirstlane(s_item[0]) : 0;   // block-uniform: SGPRs
+    int cur = DYN ? __builtin_amdgcn_readfirstlane(s_item[0]) : (int)(blockIdx.x >> 3);   // block-uniform: SGPRs
     int slot = 0;                                        // s_item[slot] takes the pull issued at the start of the current tile
     T* Cg = (T*)a.C;
     int buf = 0;
@@ -376,11 +367,11 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    int nxt = !DYN ? cur + 1 : cur < items ? __builtin_amdgcn_readfirstlane(s_item[1]) : 0;
+    int nxt = !DYN ? cur + J : cur < items ? __builtin_amdgcn_readfirstlane(s_item[1]) : 0;
     float tot1 = 0.f, tot2 = 0.f;                        // !DYN: column sums over the block's tiles (see the reduction below)
 
     while (cur < items) {
-        const int64_t m0 = tile_row0(cur);
+        const int64_t m0 = ((int64_t)(cur / tiles_f) * 8 + xcd) * BM;
         const int tf = DYN ? cur % tiles_f : tf_static;
         const int f0 = tf * BN;
         const bool has_next = nxt < items;
@@ -410,46 +401,36 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             for (int jj = 0; jj < MT; ++jj) acc[i][jj] = b0;
         }
 
-        // a range's ragged last tile: a wave whose half of the tile holds no live row skips its fragment reads and MFMAs (one
-        // scalar branch per K step; it still stages and meets the barriers).  A wave-level test only: tests per 32-row
-        // sub-tile cut the K step's basic block apart (or, with a second copy of the loop for ragged tiles, made hipcc
-        // spill 18-26 registers around it), and the lone wave on each SIMD runs its 32 MFMAs at twice the shared rate.
-        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(m0 + ws * (BM / 2) < m_end));
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned char* As = smem + buf * STAGE;
             const unsigned char* Ws = As + A_BYTES;
-            if (wave_live) {
-                uint4 fw[2][2], fs[2][MT];
+            uint4 fw[2][2], fs[2][MT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fw[0][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, h));
+            for (int i = 0; i < 2; ++i) fw[0][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, h));
 #pragma unroll
-                for (int jj = 0; jj < MT; ++jj) fs[0][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, h));
-                // the next stage's DMA requests go out while the first fragments are on their way from LDS (issued before those
-                // reads: +1 % step time; behind the first MFMA group: +3 %)
-                asm volatile("" ::: "memory");
-                if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-                else if (has_next) { set_src(nxt); stage(buf ^ 1, 0); }
+            for (int jj = 0; jj < MT; ++jj) fs[0][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, h));
+            // the next stage's DMA requests go out while the first fragments are on their way from LDS (issued before those
+            // reads: +1 % step time; behind the first MFMA group: +3 %)
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+            else if (has_next) { set_src(nxt); stage(buf ^ 1, 0); }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int cur_f = ks & 1, nxt_f = cur_f ^ 1;
-                    if (ks + 1 < 4) {
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            fw[nxt_f][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, 2 * (ks + 1) + h));
-#pragma unroll
-                        for (int jj = 0; jj < MT; ++jj)
-                            fs[nxt_f][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, 2 * (ks + 1) + h));
-                    }
-                    __builtin_amdgcn_s_setprio(1);
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cur_f = ks & 1, nxt_f = cur_f ^ 1;
+                if (ks + 1 < 4) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
+                        fw[nxt_f][i] = *(const uint4*)(Ws + lds_tile_off(wf * 64 + i * 32 + r, 2 * (ks + 1) + h));
 #pragma unroll
-                        for (int jj = 0; jj < MT; ++jj) mma_chunk<T>(fw[cur_f][i], fs[cur_f][jj], acc[i][jj]);
-                    __builtin_amdgcn_s_setprio(0);
+                    for (int jj = 0; jj < MT; ++jj)
+                        fs[nxt_f][jj] = *(const uint4*)(As + lds_tile_off(ws * (BM / 2) + jj * 32 + r, 2 * (ks + 1) + h));
                 }
-            } else {
-                if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-                else if (has_next) { set_src(nxt); stage(buf ^ 1, 0); }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < MT; ++jj) mma_chunk<T>(fw[cur_f][i], fs[cur_f][jj], acc[i][jj]);
+                __builtin_amdgcn_s_setprio(0);
             }
             if constexpr (DYN)
                 if (kt == 0 && tid == 0 && has_next) s_item[slot] = pulled;
@@ -480,31 +461,31 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             const unsigned char* Rlo = smem + (buf ^ 1) * STAGE;
             const unsigned char* Rhi = Rlo + 32768;
             const uint32_t lo = lds0 + (buf ^ 1) * STAGE, hi = lo + 32768;
-            const bool full = m0 + BM <= m_end;
-            nt256p_issue_quarter<MT>(am, m0, f0, 0, lo, wave_u, lane);
-            nt256p_issue_quarter<MT>(am, m0, f0, 1, hi, wave_u, lane);
+            const bool full = m0 + BM <= a.M;
+            nt256p_issue_quarter<MT>(a, m0, f0, 0, lo, wave_u, lane);
+            nt256p_issue_quarter<MT>(a, m0, f0, 1, hi, wave_u, lane);
             if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            nt256p_quarter<EPI, MT, 0>(am, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
+            nt256p_quarter<EPI, MT, 0>(a, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
             __syncthreads();                                                     // lo has been read by every wave
-            nt256p_issue_quarter<MT>(am, m0, f0, 2, lo, wave_u, lane);
+            nt256p_issue_quarter<MT>(a, m0, f0, 2, lo, wave_u, lane);
             if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            nt256p_quarter<EPI, MT, 1>(am, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
+            nt256p_quarter<EPI, MT, 1>(a, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
             __syncthreads();                                                     // hi has been read by every wave
-            nt256p_issue_quarter<MT>(am, m0, f0, 3, hi, wave_u, lane);
+            nt256p_issue_quarter<MT>(a, m0, f0, 3, hi, wave_u, lane);
             if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            nt256p_quarter<EPI, MT, 2>(am, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
+            nt256p_quarter<EPI, MT, 2>(a, acc, Rlo, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
             if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            nt256p_quarter<EPI, MT, 3>(am, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
+            nt256p_quarter<EPI, MT, 3>(a, acc, Rhi, bias_s, mw0, base, fw0, ws, wf, r, h, lane, dkey, qs1, qs2);
             if (has_next) __syncthreads();                                       // the next tile's second stage goes into this buffer
         } else {
             const int64_t mw0 = m0 + ws * (BM / 2);
             T* base = Cg + (mw0 + r) * a.ldc + f0 + wf * 64 + 8 * h;
-            if (m0 + BM > m_end) nt256p_convert<EPI, MT, false>(am, acc, mw0, base, r, lane, qs1, qs2);
-            else nt256p_convert<EPI, MT, true>(am, acc, mw0, base, r, lane, qs1, qs2);
+            if (m0 + BM > a.M) nt256p_convert<EPI, MT, false>(a, acc, mw0, base, r, lane, qs1, qs2);
+            else nt256p_convert<EPI, MT, true>(a, acc, mw0, base, r, lane, qs1, qs2);
         }
         if constexpr (STATS) {
             // remaining butterfly steps (lane bits 2..4)
@@ -547,20 +528,20 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmNTArgs a) {
             nxt = __builtin_amdgcn_readfirstlane(s_item[slot]);
             slot ^= 1;
         } else {
-            nxt += 1;
+            nxt += J;
         }
     }
 
     if constexpr (STATS && !DYN) {
-        // one partial row per block and column tile: row = the block's row worker (workers 0 .. ceil(M / rpw) - 1 have rows)
+        // one partial row per block and column tile: row (j / tiles_f) * 8 + xcd, the block's first sample tile
         const int j = blockIdx.x >> 3;
-        if (items > 0) {
+        if (j < items) {
             const int fl = wf * 64 + (r >> 4) * 32 + ((r >> 2) & 3) * 8 + 4 * h + (r & 3);
             red[ws * BN + fl] = tot1;
             red[(2 + ws) * BN + fl] = tot2;
             __syncthreads();
             const int which = tid / BN, col = tid % BN;
-            const int64_t prow = wk;
+            const int64_t prow = (int64_t)(j / tiles_f) * 8 + xcd;
             const int f0 = (j % tiles_f) * BN;
             const float v = red[(which * 2) * BN + col] + red[(which * 2 + 1) * BN + col];
             if constexpr (EPI == EPI_DGRAD_BN) {
@@ -620,12 +601,9 @@ static inline hipError_t launch_gemm_nt256p(GemmNTArgs a, hipStream_t st, int* s
         hipLaunchKernelGGL((gemm_nt256p_kernel<EPI, 4, true>), dim3(256), dim3(512), 0, st, a);
     } else {
         const int J = 32 - (32 % tiles_f);                       // blocks per XCD, a multiple of tiles_f
-        const int64_t workers = (int64_t)(J / tiles_f) * 8;      // row workers = at most that many partial rows
-        int64_t rpw = (a.M + workers - 1) / workers;
-        rpw = (rpw + 31) / 32 * 32;                              // whole 32-row MFMA sub-tiles
-        a.rpw = rpw;
+        const int64_t slots = (int64_t)(J / tiles_f) * 8;        // sample tiles per round = partial rows
         a.sched = nullptr;
-        if (stat_rows) *stat_rows = (int)((a.M + rpw - 1) / rpw);
+        if (stat_rows) *stat_rows = (int)(tiles_m < slots ? tiles_m : slots);
         hipLaunchKernelGGL((gemm_nt256p_kernel<EPI, 4, false>), dim3(8 * J), dim3(512), 0, st, a);
     }
     return hipGetLastError();

@@ -143,9 +143,12 @@ def test_half_batches_bracket_full_batch_loss():
 #             gradient and conv1's backward.
 # Error model: every stored tensor is one bf16 rounding (2^-9 relative) of an f32 result; a gradient that passed the
 # dropout-side path is rounded twice (g_v, then g_y).  Stated bounds (asserted, measured values printed):
-#   stored activation / gradient tensors: max |err| <= 3e-2 max|ref|, rms err <= 1e-2 rms(ref)  (operands AND weights are
-#   bf16 in the device GEMMs, f32 in the recomputation);
-#   parameter gradients (f32 accumulation of exact bf16 products over 167,936 rows): <= 2e-3 of the tensor's max.
+#   stored activation / gradient tensors: max |err| <= 1.2e-2 max|ref|, rms err <= 8e-3 rms(ref)  (operands AND weights are
+#   bf16 in the device GEMMs, f32 in the recomputation; measured 2.0e-3..5.2e-3 / 1.6e-3..3.4e-3);
+#   fc weight / bias gradients (f32 accumulation of exact bf16 products over 167,936 rows): <= 5e-5 of the tensor's max
+#   (measured <= 4.4e-6); conv2's weight gradient (its u1 operand is re-rounded to bf16 on the device) <= 4e-3 (1.2e-3);
+#   BatchNorm gamma / beta gradients: <= 1e-5 where the sums come from the weight-gradient algebra (measured ~1e-7),
+#   <= 8e-3 behind a dropout, where they are sums of bf16-rounded gradients (measured <= 3.2e-3).
 # ---------------------------------------------------------------------------------------------------------------------
 LIN = (0, 3, 6, 9, 13, 17, 21)
 BN_LIN = (2, 5, 8, 11, 15, 19, 23)
@@ -212,7 +215,7 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
     G = e.grads.views
     report = {}
     inv_keep = 1.0 / (1.0 - round(P_DROP * 65536) / 65536.0)
-    ACT_MAX, ACT_RMS, PGRAD = 3e-2, 1e-2, 2e-3
+    ACT_MAX, ACT_RMS, PGRAD = 1.2e-2, 8e-3, 5e-5
 
     def check_tensor(name, got, ref, mx=ACT_MAX, rms=ACT_RMS):
         a, b = _rel(got, ref)
@@ -278,7 +281,7 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
     z_ref = u8 @ W["emg_net.last.0.weight"].t()
     a, b = _rel(z, z_ref)
     report["fwd/proj"] = (a, b)
-    assert a < 2e-3 and b < 1e-3, ("z", a, b)                        # z is f32 on both sides: accumulation order only
+    assert a < 6e-3 and b < 4e-3, ("z", a, b)                        # z is stored in f32; the device's weights are bf16
     del bn8
 
     # ---------------- head: loss and dL/dz by autograd on the same f32 z -------------------------------------------
@@ -303,15 +306,15 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
 
     # ---------------- backward --------------------------------------------------------------------------------------
     # projection: dW = dz^T u8 (dz is stored in bf16 by the head kernel, so this bound carries its rounding)
-    check_param("bwd/last_w", G["emg_net.last.0.weight"], dz.t() @ u8, tol=4e-3)
+    check_param("bwd/last_w", G["emg_net.last.0.weight"], dz.t() @ u8, tol=1e-3)
     gv = (dz @ W["emg_net.last.0.weight"]) * masks[8] * inv_keep
     gamma = W[bnn[8] + ".weight"]
     g_ref, dg, db_ = _bn_backward(gv, acts[8], st[8][0], st[8][1], gamma, N)
     g_ref = g_ref * (acts[8] > 0)
     check_tensor("bwd/proj_dgrad+bn8 (EPI_DGRAD_ST K=64, bn_relu_bwd)", tap[8].reshape(-1)[:N * 512].reshape(N, 512), g_ref,
-                 mx=3e-2, rms=1.2e-2)                               # on top of a bf16-rounded dz
-    check_param("bwd/bn8_gamma", G[bnn[8] + ".weight"], dg, tol=6e-3)
-    check_param("bwd/bn8_beta", G[bnn[8] + ".bias"], db_, tol=6e-3)
+                 mx=1.5e-2, rms=9e-3)                               # on top of a bf16-rounded dz
+    check_param("bwd/bn8_gamma", G[bnn[8] + ".weight"], dg, tol=8e-3)
+    check_param("bwd/bn8_beta", G[bnn[8] + ".bias"], db_, tol=8e-3)
     del gv, g_ref, u8
     for L in range(8, 1, -1):
         i, Lp = L - 2, L - 1
@@ -345,8 +348,8 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
         width = 768 if Lp == 1 else 512
         got = tap[Lp].reshape(-1)[:N * width].reshape(g_ref.shape)
         check_tensor(f"bwd/fc{i + 1}_dgrad+bn{Lp} ({mode})", got, g_ref)
-        check_param(f"bwd/bn{Lp}_gamma", G[bnn[Lp] + ".weight"], dg, tol=4e-3)
-        check_param(f"bwd/bn{Lp}_beta", G[bnn[Lp] + ".bias"], db_, tol=4e-3)
+        check_param(f"bwd/bn{Lp}_gamma", G[bnn[Lp] + ".weight"], dg, tol=8e-3 if Lp >= 5 else 1e-5)
+        check_param(f"bwd/bn{Lp}_beta", G[bnn[Lp] + ".bias"], db_, tol=8e-3 if Lp >= 5 else 1e-5)
         del gin, g_ref, gy
     # conv2: tap[1] = dL/d(conv2 pre-activation) [N][12][64]
     g2 = tap[1].reshape(N, 12, 64).float()
@@ -354,7 +357,7 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
     dwc2 = torch.zeros(64, 64, 3, 3, device="cuda")
     for t in range(3):
         dwc2[:, :, 1, t] = g2.reshape(-1, 64).t() @ _shift_w(u1, t - 1).reshape(-1, 64)
-    check_param("bwd/conv2_w (conv2_wgrad)", G["emg_net.conv_emg.3.weight"], dwc2)
+    check_param("bwd/conv2_w (conv2_wgrad)", G["emg_net.conv_emg.3.weight"], dwc2, tol=4e-3)
     assert float(G["emg_net.conv_emg.3.weight"][:, :, 0, :].abs().max()) == 0.0      # rows 0 and 2 only ever meet padding
     assert float(G["emg_net.conv_emg.3.weight"][:, :, 2, :].abs().max()) == 0.0
     gu1 = sum(_shift_w(g2, 1 - t) @ wc2[:, :, t] for t in range(3))
@@ -363,8 +366,8 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
     gu1 = tap[0].reshape(N * 12, 64).float()
     g0, dg, db_ = _bn_backward(gu1, r0.reshape(N * 12, 64), st[0][0], st[0][1], W[bnn[0] + ".weight"], N * 12)
     g0 = (g0 * (r0.reshape(N * 12, 64) > 0)).reshape(N, 12, 64)
-    check_param("bwd/bn0_gamma", G[bnn[0] + ".weight"], dg, tol=4e-3)
-    check_param("bwd/bn0_beta", G[bnn[0] + ".bias"], db_, tol=4e-3)
+    check_param("bwd/bn0_gamma", G[bnn[0] + ".weight"], dg, tol=1e-5)
+    check_param("bwd/bn0_beta", G[bnn[0] + ".bias"], db_, tol=1e-5)
     check_param("bwd/conv1_b", G["emg_net.conv_emg.0.bias"], g0.reshape(-1, 64).sum(0))
     dw1 = torch.stack([(g0 * xp[:, t:t + 12].unsqueeze(-1)).reshape(-1, 64).sum(0) for t in range(3)], -1)   # (64, 3)
     check_param("bwd/conv1_w", G["emg_net.conv_emg.0.weight"][:, 0, 1, :], dw1)
@@ -402,6 +405,7 @@ def test_bf16_vs_f32_hip_argmax_agreement_at_bench_size():
     print(f"\nbf16 vs f32 HIP at {B} groups: max |dlogit| {float(d.max()):.3e}, rms {float(d.pow(2).mean().sqrt()):.3e}, "
           f"argmax agreement {agree:.4f} (median top-2 margin of the f32 logits {margin:.2e}), "
           f"loss {res['bf16'][0]:.5f} vs {res['f32'][0]:.5f};  SURVEY 8c bar (<= 2e-2, >= 99 %): "
-          f"{'PASS' if float(d.max()) <= 2e-2 and agree >= 0.99 else 'FAIL (random init: margins ~1e-3; see DESIGN.md section 2)'}")
-    assert float(d.max()) < 6e-2 and float(d.pow(2).mean().sqrt()) < 1.2e-2 and agree > 0.93
+          f"{'PASS' if float(d.max()) <= 2e-2 and agree >= 0.99 else 'FAIL at random init (the trained-model case, tests/test_gpu_parity.py, passes it; DESIGN.md section 2)'}")
+    # the maximum is taken over 6.9 M logits here (B = 16 in test_bf16_path: 27 k), so the tail reaches further: 0.1
+    assert float(d.max()) < 0.1 and float(d.pow(2).mean().sqrt()) < 1.2e-2 and agree > 0.93
     assert res["bf16"][0] == pytest.approx(res["f32"][0], rel=2e-3)
