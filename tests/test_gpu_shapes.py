@@ -7,7 +7,10 @@ of the next layer by O(2^-9 / sqrt(41)) and the normalised activations with it. 
 edge case of the kernels, the same step is also run in f32 on an input perturbed by ONE bf16-sized relative error per element
 (`pert`): the f32 path's own gradient moves by a comparable angle from that single perturbation, where the bf16 path has
 eighteen rounded tensors.  Asserted: z cosine > 0.995; gradient cosine > 0.95 below 100 groups, > 0.99 from 100 groups on;
-and the bf16 deviation stays within 60x the single-perturbation deviation of the f32 path (measured: see the printed table).
+and the bf16 deviation (1 - cos) stays within 8x the single-perturbation deviation of the f32 path.  Measured on MI355X:
+the ratio is 3.2-3.4 at EVERY size (1 group: bf16 0.9687 vs f32-perturbed 0.9906; 100 groups: 0.9940 vs 0.9982; 1001 groups:
+0.99917 vs 0.99974) -- eighteen rounded tensors against one, sqrt(18) ~ 4: the 41-window case is the same noise as every
+other size, amplified by the conditioning of a 41-row BatchNorm stack, not a small-N edge case of the kernels.
 """
 import pytest
 import torch
@@ -54,4 +57,4 @@ def test_bf16_tracks_f32_over_ragged_batch_sizes():
         assert zc > 0.995, (groups, zc)
         assert gc > (0.95 if groups < 100 else 0.99), (groups, gc)
         assert abs(la - lb) < 2e-2, (groups, la, lb)
-        assert (1 - gc) < 60 * (1 - gpc) + 2e-3, (groups, gc, gpc)
+        assert (1 - gc) < 8 * (1 - gpc) + 1e-4, (groups, gc, gpc)
