@@ -11,6 +11,7 @@
 #include "gemm_nt.cuh"
 #include "gemm_nt256.cuh"
 #include "gemm_nt256p.cuh"
+#include "gemm_ws.cuh"
 #include "gemm_tn.cuh"
 #include "gemm_tn256.cuh"
 #include "kernels_misc.cuh"
@@ -274,6 +275,10 @@ static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int
     if constexpr (sizeof(T) == 2) {
         // (dbg 64 / 128, tools only: force the dynamic / static schedule for this launch)
         const bool dyn = (a.dbg & 64) ? true : (a.dbg & 128) ? false : tile_schedule() == CP_TILES_DYNAMIC;
+        // K = 512 forward launches of a process that has the GPU to itself: the weight-stationary kernel (gemm_ws.cuh).
+        // (dbg 256, tools only: the tile-staged kernel instead; $CPNATIVE_NO_WS does the same for a whole process)
+        if (EPI == EPI_FWD && a.K == WS_K && a.lda == WS_K && a.relu && !dyn && !(a.dbg & (16 | 256)) && !getenv("CPNATIVE_NO_WS"))
+            return launch_gemm_ws<EPI_FWD>(a, st, stat_rows);
         if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows, dyn);
         if (EPI == EPI_DGRAD && a.R != nullptr && !(a.dbg & 16) && !getenv("CPNATIVE_STAGED_R_EPILOGUE")) {
             // the persistent kernel's R epilogues: BN + ReLU backward of the layer below (coef), or dropout + BN-backward sums

@@ -6,7 +6,7 @@ import sys
 
 s = open(sys.argv[1]).read().split("\n")
 key = sys.argv[2]
-start = next(i for i, l in enumerate(s) if l.startswith("_Z") and key in l and l.rstrip().endswith(":") or (l.startswith("_Z") and key in l and ": ;" in l))
+start = next(i for i, l in enumerate(s) if l.startswith("_Z") and key in l and ":" in l and not l.startswith("\t"))
 end = next(i for i in range(start + 1, len(s)) if s[i].startswith(".Lfunc_end"))
 blk = "entry"
 order = []
