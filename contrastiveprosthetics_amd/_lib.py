@@ -62,6 +62,11 @@ SYMBOLS = {
     "cp_encoder_forward": (C.c_int, [_P(cp_config), _P(cp_params), _P(cp_bn_buffers), _fp, _fp, C.c_size_t, _fp, _fp]),
     "cp_head": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t,
                           _fp, _fp, _fp, _P(cp_params), _fp]),
+    "cp_global_negatives_scratch_floats": (C.c_size_t, [C.c_int64]),
+    "cp_global_negatives": (C.c_int, [_P(cp_params), _fp, C.c_int64, _fp, _fp, _fp, _fp]),
+    "cp_head_gneg": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t,
+                               _fp, _fp, _fp, _P(cp_params), _fp, _fp]),
+    "cp_set_stats_allreduce": (C.c_int, [_fp, _fp, C.c_int32]),
     "cp_encoder_backward": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, _P(cp_params), _fp]),
     "cp_encoder_backward_ev": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, _P(cp_params), _fp, _fp]),
     "cp_vote": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp]),
@@ -96,6 +101,8 @@ SYMBOLS = {
     "cp_debug_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp,
                                 C.c_int32, _fp]),
 }
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)     # cp_allreduce_fn
 
 KERNEL_KINDS = ["gather", "prep", "conv1_fwd", "bn_finalize", "conv2_fwd", "fold", "fc_fwd", "dropout", "proj_fwd",
                 "head", "proj_bwd", "bn_bwd", "fc_wgrad", "reduce_slabs", "fc_dgrad", "conv2_wgrad", "conv2_dgrad",

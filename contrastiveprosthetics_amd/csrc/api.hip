@@ -59,6 +59,20 @@ extern "C" int cp_set_tile_schedule(int32_t mode) {
 extern "C" int cp_get_tile_schedule(void) { return tile_schedule(); }
 
 // ---------------------------------------------------------------------------------------
+// synchronised BatchNorm: the caller's sum over ranks of one row of statistics (cpnative.h)
+// ---------------------------------------------------------------------------------------
+static cp_allreduce_fn g_sync_fn = nullptr;
+static void* g_sync_user = nullptr;
+static int g_sync_world = 1;
+extern "C" int cp_set_stats_allreduce(cp_allreduce_fn fn, void* user, int32_t world) {
+    if (fn && world < 1) return fail(CP_ERR_ARG, "cp_set_stats_allreduce: world");
+    g_sync_fn = fn;
+    g_sync_user = user;
+    g_sync_world = fn ? world : 1;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // optional per-kernel-kind timing with HIP events recorded on the launch stream
 // (bench.py's live roofline measurement).  Events are created in cp_profile_enable, never
 // inside a step.  Not thread-safe: one profiled stream at a time.
@@ -148,6 +162,7 @@ struct WS {
     size_t slabs;            // f32
     size_t praw;             // f32 [512][768]: raw (un-fixed) weight-gradient product of the current layer
     size_t head_part;        // f32
+    size_t sync_loc, sync_glob;   // f32 [2][768] each: one row of statistics, this rank's and the sum over ranks (sync BN)
     size_t total;
     size_t partials_floats, slabs_floats;
 };
@@ -185,6 +200,8 @@ static WS carve(int64_t N, int dtype, float dp) {
     w.slabs = take(kSlabFloats * 4);
     w.praw = take((size_t)512 * 768 * 4);
     w.head_part = take((size_t)kHeadBlocksMax * HEAD_PART * 4);
+    w.sync_loc = take(2 * 768 * 4);
+    w.sync_glob = take(2 * 768 * 4);
     w.total = o;
     return w;
 }
@@ -313,6 +330,23 @@ struct PreReduce {
     }
 };
 
+// Synchronised BatchNorm: fold `nrows` partial rows of `width` floats into ONE row (this rank's sums, kept in ws.sync_loc),
+// copy it, and have the caller's hook sum the copy over the ranks in place (ws.sync_glob).  Returns the global row;
+// *local = this rank's row.  Stream-ordered: the hook enqueues its collective behind `st` and makes `st` wait for it.
+static int sync_row(const float* pp, int nrows, int width, unsigned char* base, const WS& w, hipStream_t st, const float** glob,
+                    const float** local) {
+    float* loc = (float*)(base + w.sync_loc);
+    float* glo = (float*)(base + w.sync_glob);
+    if (width > 2 * 768) return fail(CP_ERR_ARG, "sync_row width");
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(width)), dim3(FIN_THREADS), 0, st, pp, nrows, width, loc);
+    CKL("colsum_finalize_kernel(sync)");
+    CK(hipMemcpyAsync(glo, loc, (size_t)width * 4, hipMemcpyDeviceToDevice, st));
+    if (int e = g_sync_fn(g_sync_user, glo, width, st)) return fail(e, "the statistics all-reduce hook failed");
+    *glob = glo;
+    if (local) *local = loc;
+    return 0;
+}
+
 template <typename T>
 static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn_buffers* bn, const float* x,
                              unsigned char* base, const WS& w, float* z, hipStream_t st) {
@@ -331,6 +365,11 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const int C = kLayerC[l];
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
         const float* pp = batch_stats ? pre(nrows, 2 * C) : partials;
+        if (batch_stats && g_sync_fn) {          // synchronised BatchNorm: statistics of the GLOBAL batch
+            if (int e = sync_row(pp, nrows, 2 * C, base, w, st, &pp, nullptr)) return e;
+            nrows = 1;
+            count *= g_sync_world;
+        }
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
                            have_running ? bn->running_mean[l] : nullptr, have_running ? bn->running_var[l] : nullptr, upd,
                            batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats(l), C);
@@ -445,9 +484,49 @@ extern "C" int cp_encoder_forward(const cp_config* cfg, const cp_params* p, cons
 // ---------------------------------------------------------------------------------------
 // head
 // ---------------------------------------------------------------------------------------
+extern "C" size_t cp_global_negatives_scratch_floats(int64_t n_all_windows) {
+    return n_all_windows > 0 ? (size_t)n_all_windows + (size_t)2 * kHeadBlocksMax * GNEG_PART : 0;
+}
+
+extern "C" int cp_global_negatives(const cp_params* p, const float* z_all, int64_t n_all_windows, const int64_t* labels,
+                                   float* scratch, float* gh_out, void* stream) {
+    if (!p || !p->easy_w || !p->easy_b || !z_all || !labels || !scratch || !gh_out || n_all_windows <= 0 ||
+        n_all_windows % CP_TASKS != 0)
+        return fail(CP_ERR_ARG, "cp_global_negatives args");
+    hipStream_t st = (hipStream_t)stream;
+    float* pos = scratch;
+    float* part = scratch + n_all_windows;
+    const int blocks = grid_rows(n_all_windows, 256, kHeadBlocksMax);
+    ProfScope ps(CP_K_HEAD, st);
+    hipLaunchKernelGGL(gneg_g_kernel, dim3(blocks), dim3(256), 0, st, z_all, n_all_windows, p->easy_w, p->easy_b, labels, part, pos);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(GNEG_PART)), dim3(FIN_THREADS), 0, st, part, blocks, GNEG_PART, gh_out);
+    float* part2 = part + (size_t)kHeadBlocksMax * GNEG_PART;
+    hipLaunchKernelGGL(gneg_h_kernel, dim3(blocks), dim3(256), 0, st, pos, n_all_windows, gh_out, labels, part2);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(GNEG_PART)), dim3(FIN_THREADS), 0, st, part2, blocks, GNEG_PART, gh_out + GNEG_PART);
+    CKL("gneg kernels");
+    return 0;
+}
+
+static int head_impl(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels, int64_t n_groups,
+                     int32_t V, int32_t want_grad, void* ws, size_t ws_bytes, float* loss_correct, int32_t* pred,
+                     float* logits, cp_params* grads, const float* gneg, void* stream);
+
 extern "C" int cp_head(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels, int64_t n_groups,
                        int32_t V, int32_t want_grad, void* ws, size_t ws_bytes, float* loss_correct, int32_t* pred,
                        float* logits, cp_params* grads, void* stream) {
+    return head_impl(cfg, p, z, labels, n_groups, V, want_grad, ws, ws_bytes, loss_correct, pred, logits, grads, nullptr, stream);
+}
+
+extern "C" int cp_head_gneg(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels, int64_t n_groups,
+                            int32_t V, int32_t want_grad, void* ws, size_t ws_bytes, float* loss_correct, int32_t* pred,
+                            float* logits, cp_params* grads, const float* gh, void* stream) {
+    if (!gh || V != 1) return fail(CP_ERR_ARG, "cp_head_gneg: needs the {G, H} table of cp_global_negatives and V == 1 (training batches)");
+    return head_impl(cfg, p, z, labels, n_groups, V, want_grad, ws, ws_bytes, loss_correct, pred, logits, grads, gh, stream);
+}
+
+static int head_impl(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels, int64_t n_groups,
+                     int32_t V, int32_t want_grad, void* ws, size_t ws_bytes, float* loss_correct, int32_t* pred,
+                     float* logits, cp_params* grads, const float* gneg, void* stream) {
     WS w;
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !z || !labels || !loss_correct || !pred || V <= 0 || n_groups * CP_TASKS != cfg->n_windows)
@@ -462,6 +541,7 @@ extern "C" int cp_head(const cp_config* cfg, const cp_params* p, const float* z,
     a.z = z; a.easy_w = p->easy_w; a.easy_b = p->easy_b; a.labels = labels;
     a.G = n_groups; a.V = V; a.want_grad = want_grad; a.dz_ld = 64; a.dz = base + w.dz;
     a.logits = logits; a.pred = pred; a.partials = (float*)(base + w.head_part);
+    a.gneg = gneg;
     const int blocks = grid_rows(n_groups, HEAD_WAVES, kHeadBlocksMax);
     if (cfg->dtype == CP_BF16)
         hipLaunchKernelGGL((head_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a);
@@ -818,6 +898,21 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     int conv_dgrad_rows = 0;
     int stat_rows = tiles_n;     // partial rows holding the BN-backward sums for the next bn_bwd_finalize
     const PreReduce pre{partials, (float*)(base + w.partials2), st};
+    // BatchNorm backward, step 1 for layer l (C channels, each seen nfold times in the partial rows): sums -> coefficients of
+    // the data gradient + dgamma / dbeta.  Synchronised BatchNorm: the coefficients take the sums and the count of ALL ranks,
+    // dgamma / dbeta this rank's own sums (the gradient all-reduce adds the ranks' parts).
+    auto bwd_finalize = [&](const float* pp, int nr, double count, int l, int C, int nfold, const char* what) -> int {
+        const float* local = nullptr;
+        if (g_sync_fn) {
+            if (int e = sync_row(pp, nr, 2 * C * nfold, base, w, st, &pp, &local)) return e;
+            nr = 1;
+            count *= g_sync_world;
+        }
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nr, count, stats(l), coef, g->bn_g[l],
+                           g->bn_b[l], C, nfold, local);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail((int)e, what);
+    };
 
     {
         ProfScope ps(CP_K_PREP, st);
@@ -872,9 +967,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // no dropout behind fc7: its BN-backward sums are known (from the projection's weight gradient), so this
             // launch applies fc7's BN + ReLU backward itself, as the fc launches below do for their layer below
             int nr = stat_rows;
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, partials, nr, (double)N, stats(8), coef,
-                               g->bn_g[8], g->bn_b[8], 512, 1);
-            CKL("bn_bwd_finalize_kernel(fc7, fused)");
+            if (int e = bwd_finalize(partials, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, fused)")) return e;
             a.R = act(8); a.coef = coef; a.coef_mod = 512;
             CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
             nr = drows;
@@ -901,9 +994,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;
             const float* pp = pre(nr, 2 * 512);
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, (double)N, stats(L), coef,
-                               g->bn_g[L], g->bn_b[L], 512, 1);
-            CKL("bn_bwd_finalize_kernel");
+            if (int e = bwd_finalize(pp, nr, (double)N, L, 512, 1, "bn_bwd_finalize_kernel")) return e;
             const int gb = grid_rows(N, 256 / (512 / D::EPC), 2048);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
             nr = gb;
@@ -984,9 +1075,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 ProfScope ps(CP_K_BN_BWD, st);
                 int nr = stat_rows;
                 const float* pp = pre(nr, 2 * K);
-                hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(Cp)), dim3(FIN_THREADS), 0, st, pp, nr, (double)N * nfold, stats(Lp), coef,
-                                   g->bn_g[Lp], g->bn_b[Lp], Cp, nfold);
-                CKL("bn_bwd_finalize_kernel(fused)");
+                if (int e = bwd_finalize(pp, nr, (double)N * nfold, Lp, Cp, nfold, "bn_bwd_finalize_kernel(fused)")) return e;
             }
             a.R = act(Lp); a.coef = coef; a.coef_mod = Cp;
             int drows = 0;
@@ -1022,9 +1111,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
             const float* pp = pre(nr, 2 * 768);
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(1), coef,
-                               g->bn_g[1], g->bn_b[1], 64, 12);
-            CKL("bn_bwd_finalize_kernel(conv2)");
+            if (int e = bwd_finalize(pp, nr, (double)R12, 1, 64, 12, "bn_bwd_finalize_kernel(conv2)")) return e;
             const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
             nr = gb;
@@ -1070,9 +1157,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         ProfScope ps(CP_K_CONV1_BWD, st);
         int nr = conv_dgrad_rows;
         const float* pp = pre(nr, 2 * 64);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, (double)R12, stats(0), coef, g->bn_g[0],
-                           g->bn_b[0], 64, 1);
-        CKL("bn_bwd_finalize_kernel(conv1)");
+        if (int e = bwd_finalize(pp, nr, (double)R12, 0, 64, 1, "bn_bwd_finalize_kernel(conv1)")) return e;
         constexpr int RPP = 256 / (64 / D::EPC);                      // windows per block and pass
         const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
         const int gb = (int)((need + passes - 1) / passes);           // every block makes the same number of passes

@@ -33,7 +33,11 @@ struct HeadArgs {
     const float* zg;         // [B*41][16]
     void* dzg;               // [B*41][dzg_ld] T: dL/dzg through the normalisation (want_grad needs V == 1)
     int dzg_ld;
+    // global negatives (SURVEY 8e extension, one-hot class table only): gneg = [2][41] device floats {G, H} from
+    // gneg_* below, or nullptr = the reference's per-group column softmax
+    const float* gneg;
 };
+#define GNEG_PART 64         // stride of the {G, H} table of the global-negatives extension
 #define HEAD_PART 704        // 2 + 41*16 = 658 used, padded to a multiple of 64 for reduce_rows_kernel
 
 template <typename T, bool GLOVE = false>
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
             for (int i = lane; i < HEAD_T * HEAD_T; i += 64) lo[i] = Ls[wave][i / HEAD_T][i % HEAD_T];
         }
         // ---- column pass: lane j owns logits[:][j] -----------------------------------
-        {
+        if (a.gneg == nullptr) {
             float cm = -INFINITY;
 #pragma unroll 4
             for (int i = 0; i < HEAD_T; ++i) cm = fmaxf(cm, Ls[wave][i][li]);
@@ -157,6 +161,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
                 Cl[wave][lane] = clse;
                 loss_acc += clse - Ls[wave][tgt][lane];      // column j's target row is labels[j]
             }
+        } else if (act) {
+            // global negatives: the column of class c = Cls[j] sees its positive (row tgt of this group) and, through
+            // G[c], every window of another class in the GLOBAL batch:  -pos + log(exp(pos) + G[c])
+            const float pos = Ls[wave][tgt][lane];
+            const float den = __expf(pos) + a.gneg[Cls[wave][lane]];
+            Cl[wave][lane] = logf(den);                      // log of the column's denominator
+            loss_acc += logf(den) - pos;
         }
         __builtin_amdgcn_wave_barrier();
         if (a.want_grad) {
@@ -168,9 +179,15 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
 #pragma unroll 4
             for (int j = 0; j < HEAD_T; ++j) {
                 const float lj = Ls[wave][li][j];
-                float dl = __expf(lj - mx) * inv_se + __expf(lj - Cl[wave][j]);
-                dl -= (j == tgt) ? 1.f : 0.f;
-                dl -= (Tg[j] == li) ? 1.f : 0.f;
+                float dl = __expf(lj - mx) * inv_se - ((j == tgt) ? 1.f : 0.f);
+                if (a.gneg == nullptr) {
+                    dl += __expf(lj - Cl[wave][j]) - ((Tg[j] == li) ? 1.f : 0.f);
+                } else {
+                    // positive of its column: exp(pos)/den - 1; a negative of column class c: exp(l) * H[c], H[c] = the sum over
+                    // ALL groups of the global batch of 1/den (gneg_h_kernel); a row of the same class as the column that is
+                    // not its positive cannot occur (one window per class and group)
+                    dl += (Tg[j] == li) ? __expf(lj - Cl[wave][j]) - 1.f : __expf(lj) * a.gneg[GNEG_PART + Cls[wave][j]];
+                }
                 dl *= cscale;
                 const float* e = GLOVE ? EhW[wave][j] : Eh[Cls[wave][j]];
 #pragma unroll
@@ -286,6 +303,86 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
         for (int c = 0; c < HEAD_T; ++c) s += dEc[c][tid];
         d_easy_b[tid] = s;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Global negatives (no reference counterpart: the reference's column softmax of code/models.py:136-147 ranges
+// over the 41 windows of ONE group).  With a shared class table the logit of window n against class k is s[n][k] =
+// z_hat[n] . E_hat[k] whichever group n belongs to, so "all windows of other classes in the global batch" enter the
+// column loss of class k only through
+//     G[k] = sum over all windows n of the gathered batch with class(n) != k of exp(s[n][k])
+// and its gradient through
+//     H[k] = sum over all groups b of 1 / (exp(s[pos(b,k)][k]) + G[k]).
+// gneg_g_kernel: one thread per window of the gathered z (rank-major rows, 41 per group, position t has class labels[t]);
+// block partial rows [41]; also stores the window's positive logit.  gneg_h_kernel: the second sum, from the positives.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gneg_g_kernel(const float* __restrict__ z_all, int64_t n_all, const float* __restrict__ easy_w,
+                                                      const float* __restrict__ easy_b, const int64_t* __restrict__ labels,
+                                                      float* __restrict__ partials, float* __restrict__ pos) {
+    __shared__ float Eh[HEAD_T][HEAD_D];
+    __shared__ float acc[HEAD_T];
+    __shared__ int cls[HEAD_T];
+    const int tid = threadIdx.x;
+    if (tid < HEAD_T) {
+        float e[HEAD_D], n = 0.f;
+#pragma unroll
+        for (int d = 0; d < HEAD_D; ++d) { e[d] = easy_w[d * HEAD_T + tid] + easy_b[d]; n = fmaf(e[d], e[d], n); }
+        n = sqrtf(n);
+#pragma unroll
+        for (int d = 0; d < HEAD_D; ++d) Eh[tid][d] = e[d] / n;
+        acc[tid] = 0.f;
+        cls[tid] = (int)labels[tid];
+    }
+    __syncthreads();
+    float g[HEAD_T];
+#pragma unroll
+    for (int k = 0; k < HEAD_T; ++k) g[k] = 0.f;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + tid; n < n_all; n += (int64_t)gridDim.x * 256) {
+        const float4* zp = (const float4*)(z_all + n * HEAD_D);
+        float zh[HEAD_D], nz = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t4 = zp[q];
+            zh[4 * q] = t4.x; zh[4 * q + 1] = t4.y; zh[4 * q + 2] = t4.z; zh[4 * q + 3] = t4.w;
+        }
+#pragma unroll
+        for (int d = 0; d < HEAD_D; ++d) nz = fmaf(zh[d], zh[d], nz);
+        nz = sqrtf(nz);
+#pragma unroll
+        for (int d = 0; d < HEAD_D; ++d) zh[d] = zh[d] / nz;
+        const int c = cls[(int)(n % HEAD_T)];
+#pragma unroll
+        for (int k = 0; k < HEAD_T; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HEAD_D; ++d) s = fmaf(zh[d], Eh[k][d], s);
+            if (k == c) pos[n] = s;
+            else g[k] += __expf(s);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HEAD_T; ++k) {
+        const float v = wave_sum(g[k]);
+        if ((tid & 63) == 0) atomicAdd(&acc[k], v);
+    }
+    __syncthreads();
+    if (tid < GNEG_PART) partials[(int64_t)blockIdx.x * GNEG_PART + tid] = tid < HEAD_T ? acc[tid] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void gneg_h_kernel(const float* __restrict__ pos, int64_t n_all, const float* __restrict__ G,
+                                                      const int64_t* __restrict__ labels, float* __restrict__ partials) {
+    __shared__ float acc[HEAD_T];
+    __shared__ float Gs[HEAD_T];
+    __shared__ int cls[HEAD_T];
+    const int tid = threadIdx.x;
+    if (tid < HEAD_T) { acc[tid] = 0.f; Gs[tid] = G[tid]; cls[tid] = (int)labels[tid]; }
+    __syncthreads();
+    for (int64_t n = (int64_t)blockIdx.x * 256 + tid; n < n_all; n += (int64_t)gridDim.x * 256) {
+        const int c = cls[(int)(n % HEAD_T)];
+        atomicAdd(&acc[c], 1.0f / (__expf(pos[n]) + Gs[c]));
+    }
+    __syncthreads();
+    if (tid < GNEG_PART) partials[(int64_t)blockIdx.x * GNEG_PART + tid] = tid < HEAD_T ? acc[tid] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------

@@ -259,10 +259,13 @@ __global__ __launch_bounds__(256) void bn_dropout_apply_kernel(const T* __restri
 //   x_hat = (r - mean)*invstd;  dgamma = sum g*x_hat;  dbeta = sum g
 //   g_r = s * (g - mean(g) - x_hat * mean(g*x_hat))
 // ------------------------------------------------------------------------------------
+// local (synchronised BatchNorm only, else nullptr): ONE row [2][nfold*C] of this rank's own sums.  `partials` then holds
+// the sums over all ranks (they enter the data-gradient coefficients with the global count), while dgamma / dbeta are
+// formed from the local row: the gradient all-reduce adds the ranks' parts, as torch.nn.SyncBatchNorm's backward does.
 __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nrows, double count,
                                                               const float* __restrict__ stats, float* __restrict__ coef,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                                              int nfold) {
+                                                              int nfold, const float* __restrict__ local = nullptr) {
     // nfold > 1: the partial rows are nfold*C wide (feature = w*C + channel, conv stack seen
     // through the first Linear); the BatchNorm2d channel statistic sums over w.
     __shared__ double red[2][FIN_THREADS / 64][FIN_COLS];
@@ -291,8 +294,18 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const floa
         coef[0 * C + c] = (float)sc;
         coef[1 * C + c] = (float)(-sc * invstd * c2);
         coef[2 * C + c] = (float)(-sc * (c1 - mean * invstd * c2));
-        dgamma[c] = (float)dot;
-        dbeta[c] = (float)s1;
+        if (local != nullptr) {
+            s1 = s2 = 0;
+            for (int f = 0; f < nfold; ++f) {
+                s1 += (double)local[f * C + c];
+                s2 += (double)local[W + f * C + c];
+            }
+            dgamma[c] = (float)((s2 - mean * s1) * invstd);
+            dbeta[c] = (float)s1;
+        } else {
+            dgamma[c] = (float)dot;
+            dbeta[c] = (float)s1;
+        }
     }
 }
 

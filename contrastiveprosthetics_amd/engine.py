@@ -305,7 +305,10 @@ class Engine:
                 v.fill_(self.num_batches_tracked)
         return self.running
 
-    def head(self, z: torch.Tensor, labels: torch.Tensor, V: int, want_grad: bool, want_logits: bool = False):
+    def head(self, z: torch.Tensor, labels: torch.Tensor, V: int, want_grad: bool, want_logits: bool = False,
+             gneg: Optional[torch.Tensor] = None):
+        """gneg: the {G, H} table of global_negatives() -> the column direction of the loss ranges over the global batch
+        (cp_head_gneg); None = the reference's per-group loss (cp_head)."""
         n = z.shape[0]
         G = n // CP_TASKS
         assert labels.dtype == torch.int64 and labels.numel() * V == n
@@ -314,11 +317,62 @@ class Engine:
         pred = torch.empty(G, CP_TASKS, dtype=torch.int32, device=self.device)
         logits = torch.empty(G, CP_TASKS, CP_TASKS, dtype=torch.float32, device=self.device) if want_logits else None
         ws, nb = self._ws_args(n)
-        _lib.check(self.lib.cp_head(C.byref(cfg), C.byref(self._p), z.data_ptr(), labels.data_ptr(), G, V,
-                                    1 if want_grad else 0, ws, nb, out.data_ptr(), pred.data_ptr(),
-                                    logits.data_ptr() if want_logits else None, C.byref(self._g), self._stream()),
-                   "cp_head")
+        if gneg is None:
+            _lib.check(self.lib.cp_head(C.byref(cfg), C.byref(self._p), z.data_ptr(), labels.data_ptr(), G, V,
+                                        1 if want_grad else 0, ws, nb, out.data_ptr(), pred.data_ptr(),
+                                        logits.data_ptr() if want_logits else None, C.byref(self._g), self._stream()),
+                       "cp_head")
+        else:
+            assert gneg.dtype == torch.float32 and gneg.numel() == 128 and gneg.is_cuda
+            _lib.check(self.lib.cp_head_gneg(C.byref(cfg), C.byref(self._p), z.data_ptr(), labels.data_ptr(), G, V,
+                                             1 if want_grad else 0, ws, nb, out.data_ptr(), pred.data_ptr(),
+                                             logits.data_ptr() if want_logits else None, C.byref(self._g), gneg.data_ptr(),
+                                             self._stream()), "cp_head_gneg")
         return out, pred, logits
+
+    def global_negatives(self, z_all: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """cp_global_negatives: z_all (n_all,16) f32 = the z rows of the GLOBAL batch (dist.all_gather_rows of every rank's
+        encoder output; one rank: its own z) -> the (2,64) table {G, H} that head(..., gneg=) takes."""
+        assert z_all.dtype == torch.float32 and z_all.is_contiguous() and z_all.shape[1] == CP_D_E
+        n_all = z_all.shape[0]
+        need = self.lib.cp_global_negatives_scratch_floats(n_all)
+        if getattr(self, "_gneg_scratch", None) is None or self._gneg_scratch.numel() < need:
+            self._gneg_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+        gh = torch.empty(2, 64, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.cp_global_negatives(C.byref(self._p), z_all.data_ptr(), n_all, labels.data_ptr(),
+                                                self._gneg_scratch.data_ptr(), gh.data_ptr(), self._stream()),
+                   "cp_global_negatives")
+        return gh
+
+    # ------------------------------------------------------------------ synchronised BatchNorm (SURVEY 8e)
+    def set_sync_bn(self, allreduce=None, world: int = 1):
+        """allreduce(tensor): sums a 1-D f32 device tensor over the ranks in place (e.g. torch.distributed.all_reduce),
+        ordered on the current stream; None switches synchronised BatchNorm off.  While set, every BatchNorm of the sEMG
+        encoder normalises with the statistics of the global batch (cp_set_stats_allreduce, 18 small collectives per
+        training step).  Process-wide: one engine at a time."""
+        if allreduce is None:
+            _lib.check(self.lib.cp_set_stats_allreduce(None, None, 1), "cp_set_stats_allreduce")
+            self._sync_cb = None
+            return
+        if self.class_encoder == "glove":
+            raise _lib.CpNativeError("synchronised BatchNorm covers the sEMG encoder; the glove-angle class encoder's BatchNorm stays local")
+        eng = self
+
+        def cb(user, row_ptr, count, stream):
+            try:
+                ws = eng._ws
+                off = row_ptr - ws.data_ptr()
+                if ws is None or off < 0 or off + 4 * count > ws.numel():
+                    return 10003
+                allreduce(ws[off:off + 4 * count].view(torch.float32))
+                return 0
+            except Exception as ex:                          # never let an exception cross the C frame
+                import traceback
+                traceback.print_exc()
+                return 10004
+
+        self._sync_cb = _lib.ALLREDUCE_FN(cb)                # keep the trampoline alive
+        _lib.check(self.lib.cp_set_stats_allreduce(C.cast(self._sync_cb, C.c_void_p), None, int(world)), "cp_set_stats_allreduce")
 
     # ------------------------------------------------------------------ glove-angle class encoder (row f2)
     def _gws_args(self, rows: int):

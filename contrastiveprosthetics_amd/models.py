@@ -105,12 +105,17 @@ class _L2Fn(torch.autograd.Function):
 
 class Model(nn.Module):
     def __init__(self, params, adabn=True, train_model=True, prediction=False, glove=False, device="cuda",
-                 dtype: str = "f32", seed: int = 42, class_encoder: str = "onehot", dropout_seed: int = None):
+                 dtype: str = "f32", seed: int = 42, class_encoder: str = "onehot", dropout_seed: int = None,
+                 global_negatives: bool = False, sync_bn: bool = False):
         """class_encoder="glove" (additive): class embeddings come from the glove-angle rows that
         TaskWrapper already delivers, through the layers GLOVENet keeps as comments (code/models.py:386-391, 461),
         instead of the one-hot table.  (The reference's own `glove` flag belongs to its --prediction classifier.)
         seed initialises the parameters; dropout_seed (default: seed) keys the dropout stream -- data-parallel ranks
-        pass seed + rank there so that their shards do not share one mask (parameters are broadcast anyway)."""
+        pass seed + rank there so that their shards do not share one mask (parameters are broadcast anyway).
+        global_negatives / sync_bn (additive, SURVEY 8e, both off by default = the reference's semantics at the local
+        batch): training batches take the class->EMG direction of the loss over the z embeddings of the GLOBAL batch
+        (one RCCL all-gather per step; cp_global_negatives / cp_head_gneg) / every BatchNorm of the sEMG encoder uses the
+        statistics of the global batch (cp_set_stats_allreduce)."""
         super().__init__()
         if prediction or glove:
             raise NotImplementedError("only the contrastive mode (prediction=False, glove=False) is accelerated; "
@@ -126,6 +131,15 @@ class Model(nn.Module):
                              d_e=int(params["d_e"]), seed=seed if dropout_seed is None else dropout_seed,
                              class_encoder=class_encoder)
         self.engine.init_parameters(seed)
+        self.global_negatives = bool(global_negatives)
+        self.sync_bn = bool(sync_bn)
+        if self.global_negatives and class_encoder != "onehot":
+            raise NotImplementedError("global negatives need the shared one-hot class table")
+        from . import dist as cpdist
+        if self.sync_bn and cpdist.world_size() > 1:
+            self.engine.set_sync_bn(cpdist.all_reduce_sum_, cpdist.world_size())
+        else:
+            self.engine.set_sync_bn(None)                  # the hook is process-wide: the newest Model decides
         self.emg_net = EMGNet()
         self.glove_net = GLOVENet()
         for k in self.engine.specs:
@@ -197,7 +211,12 @@ class Model(nn.Module):
             zg = self.engine.glove_forward(GLOVE, training=self.training)
             out, pred, logits = self.engine.head_glove(z, zg, labels, V, want_grad=want_grad, want_logits=True)
         else:
-            out, pred, logits = self.engine.head(z, labels, V, want_grad=want_grad, want_logits=True)
+            gh = None
+            if self.global_negatives and self.training and V == 1:
+                # the global-batch z matrix: every rank's rows, rank-major (world 1: this rank's own z, no collective)
+                from . import dist as cpdist
+                gh = self.engine.global_negatives(cpdist.all_gather_rows(z), labels)
+            out, pred, logits = self.engine.head(z, labels, V, want_grad=want_grad, want_logits=True, gneg=gh)
         self._pending = dict(x=x, out=out, pred=pred, labels=labels, B=B, V=V, T=T, want_grad=want_grad, done=False)
         self._last_logits = logits
         return logits

@@ -85,7 +85,8 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
     # per rank so that the shards of one global batch do not share a mask
     model = Model(params=params, train_model=True, adabn=args.no_adabn, prediction=args.prediction, glove=args.glove,
                   device="cuda", dtype=args.dtype, class_encoder=getattr(args, "class_encoder", "onehot"),
-                  dropout_seed=42 + rank).to(torch.float32)
+                  dropout_seed=42 + rank, global_negatives=bool(getattr(args, "global_negatives", False)) and not solo,
+                  sync_bn=bool(getattr(args, "sync_bn", False)) and not solo).to(torch.float32)
     if load is not None:
         print("Loading model")
         model.load_state_dict(torch.load(load + ".pt", weights_only=True))
@@ -99,7 +100,8 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
     loader = GroupLoader(dataset, args.batch_size, shuffle=shuff, rank=rank, world=world, generator=gen)
     val_losses = {}
     final_val_acc = None
-    use_graph = bool(getattr(args, "graph", False)) and world == 1 and model.class_encoder == "onehot"
+    use_graph = (bool(getattr(args, "graph", False)) and world == 1 and model.class_encoder == "onehot"
+                 and not model.global_negatives)
     graph_step = None
     print("Training...")
     for e in range(epochs):
@@ -275,6 +277,12 @@ def build_parser():
     parser.add_argument("--checkpoint_dir", default="../checkpoints")
     parser.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],
                         help="glove: class embeddings from the glove-angle rows (zero-shot path, BASELINE config 3)")
+    parser.add_argument("--global_negatives", action="store_true",
+                        help="extension: the class->EMG direction of the training loss ranges over the z embeddings of the GLOBAL "
+                             "batch (one all-gather per step under data parallelism); off = the reference's per-group loss")
+    parser.add_argument("--sync_bn", action="store_true",
+                        help="extension: BatchNorm statistics over the global batch under data parallelism (18 small all-reduces "
+                             "per step); off = every rank uses its shard's statistics, the reference at B_local")
     parser.add_argument("--graph", action="store_true",
                         help="replay each training step as one captured HIP graph (single process, one-hot class encoder)")
     parser.add_argument("--hpo_pack", action="store_true",

@@ -136,6 +136,35 @@ int cp_head(const cp_config* cfg, const cp_params* p, const float* z, const int6
             int64_t n_groups, int32_t V, int32_t want_grad, void* ws, size_t ws_bytes,
             float* loss_correct, int32_t* pred, float* logits, cp_params* grads, void* stream);
 
+/* ---- global negatives (an opt-in EXTENSION of the loss, no reference counterpart) ---------------------
+ * The reference's class->EMG direction (code/models.py:136-147 on the transposed logits) is a softmax over the 41 windows
+ * of ONE group.  With this extension the column of class k of group b ranges over its positive window and every window
+ * of another class in the GLOBAL batch (all groups of all ranks):
+ *     col[b,k] = -s[b,pos_k,k] + log( exp(s[b,pos_k,k]) + G[k] ),   G[k] = sum_{all windows n, class(n) != k} exp(s[n,k])
+ * z_all (n_all_windows,16) f32: the z embeddings of the global batch in window order (the RCCL all-gather of every rank's
+ * cp_encoder_forward output; at one rank, that output itself); labels (>= 41) int64: class of position t of a group.
+ * gh_out: 128 device floats {G[64], H[64]} (41 used each; H[k] = sum over all groups of 1/(exp(pos) + G[k]) carries the
+ * gradient into the negatives).  scratch: cp_global_negatives_scratch_floats(n_all_windows) device floats.
+ * cp_head_gneg = cp_head with that table: row direction unchanged, column direction as above; gradients are those of
+ * this rank's windows (the data-parallel gradient sum adds the ranks' parts).  One-hot class table, training batches. */
+size_t cp_global_negatives_scratch_floats(int64_t n_all_windows);
+int cp_global_negatives(const cp_params* p, const float* z_all, int64_t n_all_windows, const int64_t* labels,
+                        float* scratch, float* gh_out, void* stream);
+int cp_head_gneg(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels,
+                 int64_t n_groups, int32_t V, int32_t want_grad, void* ws, size_t ws_bytes,
+                 float* loss_correct, int32_t* pred, float* logits, cp_params* grads, const float* gh, void* stream);
+
+/* ---- synchronised BatchNorm (opt-in, default off = every rank normalises with its own shard's statistics,
+ * which is the reference at B_local, code/models.py:17-35,238-243) ----------------------------------------------------
+ * While a hook is set, every BatchNorm of the sEMG encoder takes its batch statistics -- and, in the backward pass, the two
+ * sums of BatchNorm's data gradient -- over ALL ranks: the library folds its partial sums into one row of `count` floats
+ * in the workspace and calls fn(user, row, count, stream), which must add the rows of all ranks in place, ordered after
+ * the work already on `stream` and before what is enqueued on it next (torch.distributed.all_reduce on that memory does
+ * exactly this).  world = number of ranks (the element count is scaled by it).  gamma / beta gradients stay this rank's
+ * part, as in torch.nn.SyncBatchNorm.  fn == NULL removes the hook.  18 calls per training step. */
+typedef int (*cp_allreduce_fn)(void* user, void* row_dev, int64_t count, void* stream);
+int cp_set_stats_allreduce(cp_allreduce_fn fn, void* user, int32_t world);
+
 /* autograd of EMGNet (what loss.backward() does at code/train.py:105 for emg_net):
  * consumes dL/dz left in ws by cp_head, writes every emg_net gradient into `grads`. */
 int cp_encoder_backward(const cp_config* cfg, const cp_params* p, const float* x, void* ws,

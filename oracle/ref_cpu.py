@@ -373,6 +373,26 @@ class OracleModel:
         col = F.cross_entropy(logits.transpose(1, 2).reshape(-1, T), tgt)
         return ((row + col) / 2).reshape(1)
 
+    # -- global negatives: an EXTENSION, PARITY UNPINNED -- the reference has no such code.  It changes only the
+    #    class->EMG direction of Model.loss (the second contrastive_loopy_loss call, models.py:203-206, whose softmax ranges over
+    #    the 41 windows of one group): the column of class k of group b sees its positive window and every window of another
+    #    class in the WHOLE batch handed in (all groups; under data parallelism: all ranks' groups).  With one group it
+    #    reduces to the reference's loss, which is what pins it (tests/test_oracle_golden.py).
+    def loss_global_negatives(self, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """logits (Bg,41,41) of the global batch in training mode (rows = windows, columns = class embeddings)."""
+        T = logits.shape[-1]
+        lab = labels[:T]
+        tgt = lab.repeat(logits.shape[0])
+        row = F.cross_entropy(logits.reshape(-1, T), tgt)
+        pos_of_class = torch.empty(T, dtype=torch.long)
+        pos_of_class[lab] = torch.arange(T)
+        k = torch.arange(T)
+        pos = logits[:, pos_of_class, k]                                    # (Bg, T): s[b, position of class k, k]
+        neg = (lab.reshape(T, 1) != k.reshape(1, T)).to(logits.dtype)       # [window position i][class k]
+        G = (logits.exp() * neg).sum(dim=(0, 1))                            # (T,)
+        col = (-pos + torch.log(pos.exp() + G)).mean()
+        return ((row + col) / 2).reshape(1)
+
     # -- L2 regulariser (models.py:225-228, 344-349, 467-472) ----------------
     def l2_keys(self) -> Tuple[List[str], List[str]]:
         def ok(k):

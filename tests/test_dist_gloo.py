@@ -97,3 +97,81 @@ def test_two_rank_gloo(tmp_path):
     assert torch.equal(r[0]["mean"], r[1]["mean"])                       # every rank holds the same averaged gradient
     np.testing.assert_allclose(r[0]["mean"].numpy(), ((r[0]["local"] + r[1]["local"]) / 2).numpy(), rtol=1e-6, atol=1e-9)
     assert not torch.equal(r[0]["local"], r[1]["local"])                 # the shards really differed
+
+
+# ---- global negatives (SURVEY 8e extension): rank-sharded == single process on the concatenated batch ----------------
+def _gneg_local_terms(z_local, z_all, E, labels, world):
+    """What one rank computes, written the way the HIP kernels compute it (csrc/head.cuh: gneg_g_kernel, gneg_h_kernel,
+    head_kernel with a.gneg): G and H from the GATHERED z, then loss and gradients of the rank's own windows only."""
+    T = 41
+    lab = labels[:T]
+    En = E / E.norm(dim=-1, keepdim=True)
+    zn_all = z_all / z_all.norm(dim=-1, keepdim=True)
+    S_all = (zn_all @ En.t()).reshape(-1, T, T)                         # [group][position][class]
+    neg = (lab.reshape(T, 1) != torch.arange(T).reshape(1, T)).double()
+    pos_of_class = torch.empty(T, dtype=torch.long)
+    pos_of_class[lab] = torch.arange(T)
+    G = (S_all.exp() * neg).sum((0, 1))
+    pos_all = S_all[:, pos_of_class, torch.arange(T)]
+    H = (1.0 / (pos_all.exp() + G)).sum(0)
+    zn = z_local / z_local.norm(dim=-1, keepdim=True)
+    S = (zn @ En.t()).reshape(-1, T, T)
+    B = S.shape[0]
+    c = 1.0 / (2.0 * B * T)
+    P_row = torch.softmax(S, -1)
+    onehot = torch.nn.functional.one_hot(lab, T).double()               # [position][class]
+    pos = S[:, pos_of_class, torch.arange(T)]
+    den = pos.exp() + G
+    loss = (-(torch.log_softmax(S, -1) * onehot).sum() + (torch.log(den) - pos).sum()) * c
+    dl = P_row - onehot                                                 # row direction
+    dl = dl + onehot * (S.exp() / den.reshape(B, 1, T) - 1.0) + (1 - onehot) * S.exp() * H
+    dl = dl * c
+    dzn = dl @ En                                                       # (B,T,16)
+    dEn = torch.einsum("bik,bid->kd", dl, zn.reshape(B, T, 16))
+    zl = z_local.reshape(B, T, 16)
+    nz = zl.norm(dim=-1, keepdim=True)
+    dz = (dzn - zn.reshape(B, T, 16) * (zn.reshape(B, T, 16) * dzn).sum(-1, keepdim=True)) / nz
+    nE = E.norm(dim=-1, keepdim=True)
+    dE = (dEn - En * (En * dEn).sum(-1, keepdim=True)) / nE
+    return loss, dz.reshape(-1, 16), dE
+
+
+def _gneg_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from contrastiveprosthetics_amd import dist as cpdist
+    from oracle import ref_cpu as oc
+    cpdist.init_from_env("gloo")
+    Bg = 6
+    g = torch.Generator().manual_seed(11)
+    z_all_true = torch.randn(Bg * T, 16, generator=g, dtype=torch.float64)
+    E = torch.randn(T, 16, generator=g, dtype=torch.float64)
+    labels = torch.arange(T).repeat(Bg)
+    s, e = cpdist.shard_range(Bg, rank, world)
+    z_local = z_all_true[s * T:e * T].clone()
+    gathered = cpdist.all_gather_rows(z_local)                          # the collective under test
+    assert torch.equal(gathered, z_all_true)
+    loss, dz, dE = _gneg_local_terms(z_local, gathered, E, labels, world)
+    # single-process definition on the concatenated batch (oracle, autograd)
+    za = z_all_true.clone().requires_grad_(True)
+    Ea = E.clone().requires_grad_(True)
+    logits = ((za / za.norm(dim=-1, keepdim=True)) @ (Ea / Ea.norm(dim=-1, keepdim=True)).t()).reshape(Bg, T, T)
+    m = oc.OracleModel(oc.init_state_dict(0, 16, True), BEST, adabn=True)
+    ref = m.loss_global_negatives(logits, labels)
+    ref.backward()
+    # this rank's windows: the kernel gradient, averaged over ranks by the optimiser (grad_scale = 1/world), is the global one
+    np.testing.assert_allclose((dz / world).numpy(), za.grad[s * T:e * T].numpy(), rtol=1e-9, atol=1e-12)
+    tot = torch.stack([loss.reshape(()), torch.zeros((), dtype=torch.float64)])
+    cpdist.all_reduce_sum_(tot)
+    assert tot[0].item() / world == pytest.approx(ref.item(), rel=1e-12)
+    dEs = dE.clone()
+    cpdist.all_reduce_sum_(dEs)
+    np.testing.assert_allclose((dEs / world).numpy(), Ea.grad.numpy(), rtol=1e-9, atol=1e-12)
+    open(os.path.join(out_dir, f"gneg_ok{rank}"), "w").write("ok")
+    cpdist.shutdown()
+
+
+def test_global_negatives_sharded_equals_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_gneg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f"gneg_ok{r}") for r in range(2))

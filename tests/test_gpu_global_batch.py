@@ -1,0 +1,147 @@
+"""SURVEY 8e extensions on the real kernels: --global_negatives (cp_global_negatives + cp_head_gneg) against the oracle's
+definition, and --sync_bn (cp_set_stats_allreduce) as "2 ranks x B/2 groups == 1 rank x B groups".  The GPU box has one card:
+the two ranks share it and the collectives go through gloo, as in test_gpu_ddp_rehearsal.py; what is checked is the arithmetic
+of the sharded path, not RCCL."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as oc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = 41
+BEST = dict(d_e=16, lr_emg=9.761e-4, reg_emg=7.103e-5, dp_emg=0.0, lr_glove=2.653e-3, reg_glove=2.840e-6, dp_glove=0.0)
+
+
+def randn(seed, shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("adabn", [False, True])
+def test_global_negatives_head_matches_oracle(adabn):
+    from contrastiveprosthetics_amd.engine import Engine
+    from test_gpu_parity import device_relu_masks
+    B = 8
+    sd = oc.init_state_dict(23, 16, adabn)
+    EMG = randn(77, (B, T, 1, 1, 12))
+    label = torch.arange(T).repeat(B)
+    e = Engine(adabn=adabn, dtype="f32", dp_emg=0.0, device="cuda")
+    e.load_named(sd)
+    x = EMG.reshape(-1, 12).cuda()
+    e.grads.flat.zero_()
+    z = e.encoder_forward(x, training=True)
+    gh = e.global_negatives(z, label.cuda())
+    out, pred, logits = e.head(z, label.cuda(), 1, want_grad=True, want_logits=True, gneg=gh)
+    e.encoder_backward(x)
+    torch.cuda.synchronize()
+    m = oc.OracleModel(sd, BEST, adabn=adabn, requires_grad=True)
+    ref_logits = m.forward(EMG, torch.zeros(B, T, 20), label, relu_masks=device_relu_masks(e))
+    ref = m.loss_global_negatives(ref_logits, label)
+    ref.backward()
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.detach().numpy(), atol=2e-5, rtol=0)
+    assert out[0].item() == pytest.approx(ref.item(), rel=3e-6)
+    # the table itself: G[k] = sum over windows of other classes of exp(s[., k])
+    S = ref_logits.detach().double()
+    neg = (torch.arange(T).reshape(T, 1) != torch.arange(T).reshape(1, T)).double()
+    np.testing.assert_allclose(gh[0, :T].cpu().numpy(), (S.exp() * neg).sum((0, 1)).numpy(), rtol=2e-5)
+    for k in e.specs:
+        g_ref = m.sd[k].grad
+        if g_ref is None:
+            continue
+        scale = float(g_ref.abs().max()) + 1e-12
+        err = float((e.grads.views[k].cpu() - g_ref).abs().max()) / scale
+        assert err < 2e-4, f"{k}: {err:.3e}"
+    # and it is a different loss from the reference's as soon as there is more than one group
+    assert abs(out[0].item() - m.loss_vectorized(ref_logits.detach(), label).item()) > 1e-3
+
+
+def test_model_flag_global_negatives_trains():
+    from contrastiveprosthetics_amd.models import Model
+    m = Model(dict(BEST), adabn=False, device="cuda", dtype="bf16", global_negatives=True).to(torch.float32)
+    m.set_train()
+    g = torch.Generator().manual_seed(3)
+    mu = torch.randn(T, 12, generator=g)
+    losses = []
+    for s in range(30):
+        EMG = (mu[None] + 0.7 * torch.randn(32, T, 12, generator=g)).reshape(32, T, 1, 1, 12).cuda()
+        label = torch.arange(T).repeat(32).cuda()
+        loss = m.loss(m.forward(EMG, None, label), label)
+        m.backward()
+        m.optimizer_step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] - 0.2 and np.isfinite(losses).all()
+
+
+WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["CP_ROOT"])
+import torch.distributed as td
+from contrastiveprosthetics_amd import dist as cpdist
+from contrastiveprosthetics_amd.engine import Engine
+cpdist.init_from_env()
+rank, world = cpdist.rank(), cpdist.world_size()
+T, B = 41, int(os.environ["CP_B"])
+g = torch.Generator().manual_seed(5)
+x_all = (torch.randn(T, 12, generator=g)[None] + torch.randn(B, T, 12, generator=g)).reshape(B * T, 12)
+s, e_ = cpdist.shard_range(B, rank, world)
+x = x_all[s * T:e_ * T].contiguous().cuda()
+labels = torch.arange(T).repeat(e_ - s).cuda()
+eng = Engine(adabn=False, dtype=os.environ["CP_DTYPE"], dp_emg=0.0, device="cuda", seed=3)
+eng.init_parameters(11)
+if world > 1:
+    eng.set_sync_bn(cpdist.all_reduce_sum_, world)
+eng.grads.flat.zero_()
+z = eng.encoder_forward(x, training=True)
+out, pred, _ = eng.head(z, labels, 1, want_grad=True)
+eng.encoder_backward(x)
+torch.cuda.synchronize()
+grads = eng.grads.flat.clone()
+loss = out[0:1].clone()
+if world > 1:
+    td.all_reduce(grads); grads /= world
+    td.all_reduce(loss); loss /= world
+    zs = [torch.empty_like(z) for _ in range(world)]
+    td.all_gather(zs, z)
+    z = torch.cat(zs)
+if rank == 0:
+    torch.save(dict(z=z.cpu(), grads=grads.cpu(), loss=loss.cpu(), running={k: v.cpu() for k, v in eng.running_state().items()}),
+               os.path.join(os.environ["CP_OUT"], f"w{world}.pt"))
+eng.set_sync_bn(None)
+cpdist.shutdown()
+"""
+
+
+def _run(nproc, out, port, B, dtype):
+    os.makedirs(out, exist_ok=True)
+    script = os.path.join(out, "worker.py")
+    open(script, "w").write(WORKER)
+    env = dict(os.environ, CP_ROOT=ROOT, CP_OUT=str(out), CP_DIST_BACKEND="gloo", CP_B=str(B), CP_DTYPE=dtype)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+@pytest.mark.timeout(900)
+def test_sync_bn_two_ranks_equal_one_rank_on_the_whole_batch(tmp_path):
+    """f32: 2 ranks x 24 groups with synchronised BatchNorm == 1 rank x 48 groups, to fp32 rounding (the two runs add the
+    same per-row terms in a different grouping): embeddings, loss, every gradient after the data-parallel average, and the
+    running statistics."""
+    _run(2, tmp_path, 29751, 48, "f32")
+    _run(1, tmp_path, 29752, 48, "f32")
+    two = torch.load(tmp_path / "w2.pt", weights_only=True)
+    one = torch.load(tmp_path / "w1.pt", weights_only=True)
+    np.testing.assert_allclose(two["z"].numpy(), one["z"].numpy(), atol=3e-5, rtol=1e-4)
+    assert two["loss"].item() == pytest.approx(one["loss"].item(), rel=1e-5)
+    ga, gb = two["grads"], one["grads"]
+    assert float((ga - gb).abs().max()) < 3e-4 * float(gb.abs().max())
+    cos = float((ga.double() @ gb.double()) / (ga.double().norm() * gb.double().norm()))
+    assert cos > 0.99999, cos
+    for k, v in one["running"].items():
+        if v.dtype.is_floating_point:
+            np.testing.assert_allclose(two["running"][k].numpy(), v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)

@@ -165,3 +165,17 @@ def test_reference_stored_outputs_structure():
     db = oc.OracleDB23(*oc.synthetic_resident(1, glove_d=4))
     db.set_mode("test")
     assert db.D == 48 and db.tensor.shape == (1968, 25, 12)
+
+
+def test_global_negatives_reduces_to_the_reference_loss_for_one_group(golden_dir):
+    """The global-negatives extension (parity unpinned by construction) is anchored on the one case the reference covers:
+    with a single group its column softmax is the reference's, so the value must equal Model.loss on the reference's own
+    logits (fixture) group by group."""
+    g = np.load(os.path.join(golden_dir, "train_B8_stockbn.npz"))
+    logits = torch.from_numpy(g["logits"])
+    label = torch.arange(41).repeat(logits.shape[0])
+    m = oc.OracleModel(oc.init_state_dict(0, 16, False), dict(reg_emg=0, reg_glove=0), adabn=False)
+    per_group = [m.loss_global_negatives(logits[b:b + 1], label).item() for b in range(logits.shape[0])]
+    assert np.mean(per_group) == pytest.approx(float(g["loss"]), rel=1e-6)
+    # more negatives can only raise the column term
+    assert m.loss_global_negatives(logits, label).item() > float(g["loss"])
