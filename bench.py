@@ -7,8 +7,12 @@
 
 One step = one full optimisation step of code/train.py:95-108 on one batch of synthetic
 Ninapro-shaped windows already resident in HBM: group gather -> EMG encoder forward ->
-(N>1: RCCL all-gather of the z embeddings) -> class encoder + 41x41 logits + symmetric CE ->
-backward -> (N>1: RCCL all-reduce of the 8 MB flat gradient) -> L2 regulariser + 2 x Adam.
+(N>1: RCCL all-gather of the z embeddings, read by the global-negatives column loss) -> class encoder +
+41x41 logits + symmetric CE -> backward -> (N>1: RCCL all-reduce of the 8 MB flat gradient) -> L2 regulariser + 2 x Adam.
+N = 1 is BASELINE config[1] with the reference's per-group loss and no collective.  N > 1 is config[2] ("global batch
+... with RCCL z all-gather"): the gathered z matrix feeds the global-negatives extension of the class->EMG direction
+(cp_global_negatives + cp_head_gneg, the same code path as train.py --global_negatives); --global_negatives off drops
+the collective and the extension, on forces them at N = 1 (where the "gathered" matrix is the rank's own z).
 Workload at every N: BASELINE config[1] per GPU ("synthetic 12-ch sEMG, 41-class one-hot, batch
 4096, bf16"): 4096 groups = 167,936 windows per GPU per step (weak scaling; config[2] is N=8).
 
@@ -132,6 +136,9 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel-kind times to stderr")
     ap.add_argument("--profile_every", type=int, default=4,
                     help="bracket the fc GEMM launches with HIP events (the live roofline numbers) on every n-th timed step")
+    ap.add_argument("--global_negatives", default="auto", choices=["auto", "on", "off"],
+                    help="auto: on when N > 1 (BASELINE config[2] names the z all-gather; it must have a reader), off at N = 1")
+    ap.add_argument("--sync_bn", action="store_true", help="BatchNorm statistics over the global batch (18 small all-reduces per step)")
     ap.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],
                     help="glove = BASELINE config 3 (glove-angle class encoder); the default line is config 1 (one-hot)")
     args = ap.parse_args()
@@ -179,7 +186,10 @@ def main():
     labels = torch.arange(T).repeat(B).to(dev)
     total = args.warmup + args.steps + 2
     perms = [torch.randperm(D, generator=g)[:B].to(dev) for _ in range(total)]
-    z_all = torch.empty(world * N, 16, device=dev) if use_dist else None
+    gneg = args.class_encoder == "onehot" and (args.global_negatives == "on" or (args.global_negatives == "auto" and use_dist))
+    z_all = torch.empty(world * N, 16, device=dev) if (use_dist and gneg) else None
+    if args.sync_bn and use_dist:
+        eng.set_sync_bn(lambda t: dist.all_reduce(t), world)
     state = {}
     glove_rows = None
     if args.class_encoder == "glove":          # per-(group, class) glove-angle rows: class mean + within-class spread
@@ -194,29 +204,26 @@ def main():
     def step(i):
         x = eng.gather(table, emg_rand, perms[i], 1)
         z = eng.encoder_forward(x, training=True)
-        work = None
-        if use_dist:
-            # global-batch z all-gather over xGMI (north_star).  Under the reference's per-group loss every
-            # rank scores its own slice of the gathered matrix, which it already holds (parity-neutral,
-            # SURVEY.md 8e), so the collective runs on RCCL's stream BESIDE the backward pass and is only
-            # waited for at the end of the step.
-            work = dist.all_gather_into_tensor(z_all, z, async_op=True)
+        gh = None
+        if gneg:
+            # global-batch z matrix over xGMI (north_star): every rank's rows, rank-major; its reader is the column
+            # direction of the loss (all windows of other classes in the global batch are negatives)
+            if use_dist:
+                dist.all_gather_into_tensor(z_all, z)
+            gh = eng.global_negatives(z_all if use_dist else z, labels)
         if glove_rows is not None:
             zg = eng.glove_forward(glove_rows, training=True)
             out, pred, _ = eng.head_glove(z, zg, labels, 1, want_grad=True)
             eng.glove_backward()             # first: its gradients sit in the bucket that encoder_backward's event releases
             eng.encoder_backward(x)
         else:
-            out, pred, _ = eng.head(z, labels, 1, want_grad=True)
+            out, pred, _ = eng.head(z, labels, 1, want_grad=True, gneg=gh)
             eng.encoder_backward(x)
         if use_dist:
             # the 8 MB gradient sum in two buckets: everything but the conv stack's 0.15 MB starts behind an event the
             # backward call records before its conv kernels (~0.5 ms of them); averaged by grad_scale inside Adam
             reduce_grads()
         eng.adam_step(params, grad_scale=1.0 / world)
-        if work is not None:
-            work.wait()
-            state["z_all"] = z_all
         state["out"] = out
 
     def barrier():
@@ -310,7 +317,9 @@ def main():
                                         f"({N} windows/GPU/step), {'AdaBN' if args.adabn else 'stock BN (--no_adabn)'}, "
                                         f"dp_emg={args.dp_emg}, d_e=16, random-init weights",
                                global_batch_groups=world * B, windows_per_step=world * N,
-                               parallelism=f"dp{world}" + (" + z all-gather + flat-gradient all-reduce (RCCL)" if world > 1 else ""),
+                               parallelism=f"dp{world}" + ((" + z all-gather" if gneg else "") + " + flat-gradient all-reduce (RCCL)"
+                                                           + (" + synchronised BatchNorm" if args.sync_bn else "") if world > 1 else ""),
+                               loss="global negatives (class->EMG direction over the gathered z)" if gneg else "reference per-group loss",
                                tile_schedule="dynamic" if eng.lib.cp_get_tile_schedule() else "static"),
                    loss=loss, train_acc=correct / N, roofline=roof,
                    steps_spread=dict(min_ms=step_ms[0], median_ms=step_ms[len(step_ms) // 2], max_ms=step_ms[-1],

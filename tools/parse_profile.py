@@ -3,6 +3,13 @@
 
   kernel stats :  python tools/parse_profile.py stats  <dir with *_kernel_stats.csv>  profiles/rNN_kernel_stats.csv
   HBM traffic  :  python tools/parse_profile.py traffic <fetch dir> <write dir> profiles/rNN_traffic.json
+  MFMA busy    :  python tools/parse_profile.py mfma <sq counter dir> profiles/rNN_mfma.json
+
+MFMA busy: a --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass (own run, --kernel-trace only).  Per the guide
+SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles summed over the SIMDs (32 per v_mfma_f32_32x32x16_bf16) and
+GRBM_GUI_ACTIVE is the sum of the 8 XCDs' active clocks, so for a launch
+    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 1024 SIMDs)
+and SQ_VALU_MFMA_BUSY_CYCLES / 32 is the number of MFMA instructions it issued (checked against the algorithmic count).
 
 Traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from
 separate --pmc passes (they do not fit one pass), are in KiB, and on gfx950 FETCH_SIZE reports exactly half
@@ -89,6 +96,26 @@ def main():
                        kernels=out), open(sys.argv[4], "w"), indent=1)
         tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
         print("total HBM bytes over the profiled run: %.2f GB" % (tot / 1e9))
+    elif mode == "mfma":
+        d = sys.argv[2]
+        cc = one(os.path.join(d, "**", "*_counter_collection.csv"), required=False)
+        get = (lambda c: per_kernel(cc, c)) if cc else (lambda c: per_kernel_db(d, c))
+        busy, sq, gui = get("SQ_VALU_MFMA_BUSY_CYCLES"), get("SQ_BUSY_CYCLES"), get("GRBM_GUI_ACTIVE")
+        out = {}
+        for k in sorted(busy):
+            n = max(busy[k][1], 1)
+            b = busy[k][0] / n
+            g = gui[k][0] / max(gui[k][1], 1) if k in gui else 0.0
+            if b <= 0:
+                continue
+            out[k] = dict(launches=int(n), mfma_busy_cycles_per_launch=b, mfma_instructions_per_launch=b / 32.0,
+                          gui_active_per_launch=g, sq_busy_cycles_per_launch=sq[k][0] / max(sq[k][1], 1) if k in sq else None,
+                          mfma_busy_frac=(b / ((g / 8.0) * 1024.0)) if g > 0 else None)
+        json.dump(dict(note="SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 1024 SIMDs) per launch; busy / 32 = MFMA instructions "
+                            "(v_mfma_f32_32x32x16_bf16)", kernels=out), open(sys.argv[3], "w"), indent=1)
+        for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"])[:8]:
+            print("%-60s busy frac %s  MFMAs/launch %.3g" % (k[:60], "%.3f" % v["mfma_busy_frac"] if v["mfma_busy_frac"] else "n/a",
+                                                              v["mfma_instructions_per_launch"]))
     else:
         raise SystemExit(__doc__)
 
