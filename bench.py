@@ -41,7 +41,8 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 # profiler kind -> (the ONE kernel it times, as rocprofv3 names it; fc layer indices it runs on when dropout is on / off)
 # ({dyn} = the tile schedule, include/cpnative.h cp_set_tile_schedule: "false" static, "true" dynamic)
 GEMM_KERNELS = {
-    "fc_fwd": "gemm_nt256p_kernel<0, 4, {dyn}>",          # persistent, bias + ReLU + BN sums in the epilogue
+    "fc_fwd_ws": "gemm_ws_kernel<0, 4>",                  # weight-stationary forward, fc2..fc7 (K = 512), static schedule
+    "fc_fwd": "gemm_nt256p_kernel<0, 4, {dyn}>",          # persistent, bias + ReLU + BN sums in the epilogue: fc1 (K = 768)
     "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
     "fc_dgrad_bn": "gemm_nt256p_kernel<3, 4, {dyn}>",     # persistent, + BN/ReLU backward of the layer below against the saved activation
     "fc_dgrad_stats": "gemm_nt256p_kernel<4, 4, {dyn}>",  # persistent, behind a dropout: mask + BN-backward sums against the saved activation
@@ -56,8 +57,11 @@ def gemm_model(kind: str, n: int, es: int, dropout: bool):
     of fc5..fc7: their data-gradient launches (kind fc_dgrad_stats) also read the saved activation; the
     others (kind fc_dgrad) get the BN-backward sums from the weight gradient and read no N-sized tensor for them."""
     ks = [768] + [512] * 6
-    if kind == "fc_fwd":            # read input, write post-ReLU output
-        layers, per = range(7), lambda k: k + 512
+    ws = es == 2 and not os.environ.get("CPNATIVE_NO_WS") and os.environ.get("CPNATIVE_TILE_SCHEDULE") != "dynamic"
+    if kind == "fc_fwd_ws":         # read input, write post-ReLU output: the K = 512 layers on the weight-stationary kernel
+        layers, per = (range(1, 7) if ws else range(0)), lambda k: k + 512
+    elif kind == "fc_fwd":          # the same on the tile-staged persistent kernel: fc1 (K = 768), or every layer without the ws kernel
+        layers, per = (range(0, 1) if ws else range(7)), lambda k: k + 512
     elif kind == "fc_dgrad":        # read g_y, write g_v (only with CPNATIVE_UNFUSED_BN_BWD: the plain persistent launch)
         unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD"))
         layers, per = ((range(4) if dropout else range(7)) if unfused else range(0)), lambda k: 512 + k
@@ -233,7 +237,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    gemm_kinds = ["fc_fwd", "fc_dgrad", "fc_dgrad_bn", "fc_dgrad_stats", "fc_wgrad"]
+    gemm_kinds = ["fc_fwd_ws", "fc_fwd", "fc_dgrad", "fc_dgrad_bn", "fc_dgrad_stats", "fc_wgrad"]
     eng.profile_enable(gemm_kinds, max_records=64 * (args.steps + 1))
     # one event per step boundary on the launch stream: min / median / max step time inside the timed region (the same
     # launch moves by +-10 % with the clock state of the box; the spread says how steady this run was)
@@ -277,6 +281,12 @@ def main():
         es = 2 if args.dtype == "bf16" else 4
         dom = max(gemm_kinds, key=lambda k: prof.get(k, (0.0, 0))[0])
         ms, launches = prof[dom]
+        mfma_busy = None                 # counter evidence, from the committed SQ pass of this same command (tools/profile_round.sh)
+        mpath = os.path.join(ROOT, "profiles", "r02_mfma.json")
+        if args.dtype == "bf16" and B == 4096 and os.path.exists(mpath):
+            for k, v in json.load(open(mpath))["kernels"].items():
+                if GEMM_KERNELS[dom].format(dyn="true" if eng.lib.cp_get_tile_schedule() else "false") in k:
+                    mfma_busy = v["mfma_busy_frac"]
         avg_s = ms / launches / 1e3
         byts, flops = gemm_model(dom, N, es, args.dp_emg > 0)
         gbs = byts / avg_s / 1e9
@@ -287,7 +297,7 @@ def main():
         traffic = None
         dyn = "true" if eng.lib.cp_get_tile_schedule() else "false"
         kname = GEMM_KERNELS[dom].format(dyn=dyn)
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if args.dtype == "bf16" and B == 4096 and os.path.exists(tpath):
             for k, v in json.load(open(tpath))["kernels"].items():
                 if kname in k:
@@ -305,7 +315,7 @@ def main():
                     unit="GB/s" if bound == "hbm" else "TFLOP/s",
                     frac=(gbs / HBM_PEAK_GBS) if bound == "hbm" else (tfl / mfma_peak), traffic=traffic,
                     algorithmic_bytes=byts,
-                    mfma_tflops=tfl, mfma_frac=tfl / mfma_peak, hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
+                    mfma_tflops=tfl, mfma_frac=tfl / mfma_peak, mfma_busy_frac=mfma_busy, hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
                     gemm_ms_per_step={k: prof[k][0] / profiled_steps for k in gemm_kinds if k in prof},
                     profiled_steps=profiled_steps,
                     per_kernel=per_kernel)

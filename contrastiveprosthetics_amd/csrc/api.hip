@@ -434,7 +434,9 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         a.partials = partials;
         int nrows = 0;
         {
-            ProfScope ps(CP_K_FC_FWD, st);
+            // (profiler kinds name ONE kernel each: K = 512 bf16 launches under the static schedule run gemm_ws_kernel)
+            const bool ws = sizeof(T) == 2 && K == WS_K && tile_schedule() != CP_TILES_DYNAMIC && !getenv("CPNATIVE_NO_WS");
+            ProfScope ps(ws ? CP_K_FC_FWD_WS : CP_K_FC_FWD, st);
             CK((launch_fc_gemm<T, EPI_FWD>(a, st, &nrows)));
         }
         if (int e = finalize(L, nrows, (double)N)) return e;

@@ -288,7 +288,9 @@ enum {
     CP_K_FOLD = 5, CP_K_FC_FWD = 6, CP_K_DROPOUT = 7, CP_K_PROJ_FWD = 8, CP_K_HEAD = 9,
     CP_K_PROJ_BWD = 10, CP_K_BN_BWD = 11, CP_K_FC_WGRAD = 12, CP_K_REDUCE_SLABS = 13,
     CP_K_FC_DGRAD = 14, CP_K_CONV2_WGRAD = 15, CP_K_CONV2_DGRAD = 16, CP_K_CONV1_BWD = 17,
-    CP_K_OPT = 18, CP_K_FC_DGRAD_STATS = 19, CP_K_FC_DGRAD_BN = 20, CP_K_COUNT = 21
+    CP_K_OPT = 18, CP_K_FC_DGRAD_STATS = 19, CP_K_FC_DGRAD_BN = 20,
+    CP_K_FC_FWD_WS = 21,         /* forward fc launches that ran the weight-stationary kernel (K = 512: fc2..fc7) */
+    CP_K_COUNT = 22
 };
 int cp_profile_enable(uint64_t kind_mask, int32_t max_records);
 int cp_profile_disable(void);

@@ -22,7 +22,7 @@ def test_records_survive_pause_and_resume():
         e.head(z, labels, 1, want_grad=True)
         e.encoder_backward(x)
 
-    kinds = ["fc_fwd", "fc_wgrad"]
+    kinds = ["fc_fwd", "fc_fwd_ws", "fc_wgrad"]
     e.profile_enable(kinds, max_records=256)
     step()
     e.profile_disable()
@@ -33,7 +33,8 @@ def test_records_survive_pause_and_resume():
     torch.cuda.synchronize()
     prof = e.profile_summary()
     assert set(prof) == set(kinds)
-    assert prof["fc_fwd"][1] == 2 * 7       # seven fc layers, two recorded steps
+    # seven fc layers, two recorded steps: fc1 (K = 768) on the tile-staged kernel, fc2..fc7 on the weight-stationary one
+    assert prof["fc_fwd"][1] == 2 * 1 and prof["fc_fwd_ws"][1] == 2 * 6
     assert prof["fc_wgrad"][1] == 2 * 5     # bf16 with dropout: fc7+fc6 and fc5+fc4 share a launch each
     assert all(ms > 0 for ms, _ in prof.values())
     e.profile_enable(kinds, max_records=256)  # starts over
