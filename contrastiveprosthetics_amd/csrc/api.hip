@@ -297,6 +297,10 @@ static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int
         if (EPI == EPI_FWD && a.K == WS_K && a.lda == WS_K && a.relu && !dyn && !(a.dbg & (16 | 256)) && !getenv("CPNATIVE_NO_WS"))
             return launch_gemm_ws<EPI_FWD>(a, st, stat_rows);
         if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows, dyn);
+        // BatchNorm + ReLU backward in the data-gradient epilogue, static schedule: the weight-stationary form (gemm_ws.cuh)
+        if (EPI == EPI_DGRAD && a.R != nullptr && a.coef != nullptr && a.K == WS_K && a.lda == WS_K && !dyn && !(a.dbg & (16 | 256)) &&
+            !getenv("CPNATIVE_NO_WS") && !getenv("CPNATIVE_NO_WSD"))
+            return launch_gemm_wsd_bn(a, st, stat_rows);
         if (EPI == EPI_DGRAD && a.R != nullptr && !(a.dbg & 16) && !getenv("CPNATIVE_STAGED_R_EPILOGUE")) {
             // the persistent kernel's R epilogues: BN + ReLU backward of the layer below (coef), or dropout + BN-backward sums
             return a.coef ? launch_gemm_nt256p<EPI_DGRAD_BN>(a, st, stat_rows, dyn) : launch_gemm_nt256p<EPI_DGRAD_ST>(a, st, stat_rows, dyn);
