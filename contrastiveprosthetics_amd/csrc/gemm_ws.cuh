@@ -291,6 +291,200 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmNTAr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The forward kernel on v_mfma_f32_16x16x32_bf16.  Under the chip's power cap the 16x16x32 shape delivers 1.12-1.15x the
+// FLOP/s of 32x32x16 at equal cycles per FLOP (guide, "DVFS give-back" item 7), and this kernel's floor IS that cap.
+// Same tiles, same LDS image, same fragment-read count (per 32 k: 4 reads of 16 samples x 32 k feed 16 MFMAs); what changes
+// is the accumulator layout -- register e of tile (ft, st) = feature ft*16 + 4*(lane>>4) + e of sample st*16 + (lane&15) --
+// and with it the epilogue: v_permlane16_swap pairs the feature tiles ft, ft+1 so that a lane owns 8 consecutive features
+// (one store instruction = 16 rows x 64 contiguous bytes instead of 32 x 32), and the BatchNorm sums are summed over the 4
+// sample tiles in the lane first and folded over the 16 sample lanes once per tile (two DPP steps + two ds_swizzle steps:
+// 16 values -> 1), carried in ONE register per statistic.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+// 48-row tiles (3 sample tiles of 16): with 64 rows the two accumulator sets (128 registers) + 256 weight registers + fragments
+// left hipcc 24 registers short (6 weight fragments spilled and reloaded every tile -- and spills are fatal here, see above)
+#define WS16_RT 48
+#define WS16_ST (WS16_RT / 16)
+#define WS16_TILE_BYTES (WS16_RT * WS_K * 2)
+struct Ws16Acc {
+    f32x4_t t[4][WS16_ST];   // [16-feature tile ft][16-sample tile st]
+};
+
+// halving butterfly over a DPP row of 16 lanes: in = 8 per-lane values, out = the row's total of value (lane & 7) (lanes s and
+// s ^ 8 end with the same number)
+__device__ __forceinline__ float row16_fold8(float (&v)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v[p] = (b0 ? v[2 * p + 1] : v[2 * p]) + dpp_quad<0xB1>(b0 ? v[2 * p] : v[2 * p + 1]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) v[p] = (b1 ? v[2 * p + 1] : v[2 * p]) + dpp_quad<0x4E>(b1 ? v[2 * p] : v[2 * p + 1]);
+    const float give = b2 ? v[0] : v[1];
+    const float w = (b2 ? v[1] : v[0]) + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(give), 0x101F));            // lane ^ 4
+    return w + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(w), 0x201F));                                          // lane ^ 8
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
+    constexpr int K = WS_K, KB = K / 32, RPW = WS16_RT / 4, ST = WS16_ST;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WS16_TILE_BYTES + 768 * 4];
+    float* bias_s = (float*)(smem + 2 * WS16_TILE_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, q4 = lane >> 4;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nfb = a.F >> 8;
+    const int nwk = 32 / nfb;
+    const int fb = j % nfb, wkr = j / nfb;
+    const int64_t tiles = (a.M + WS16_RT - 1) / WS16_RT;
+    const int first = wkr * 8 + xcd, stride = nwk * 8;
+    const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
+    for (int q = tid; q < a.F; q += 256) bias_s[q] = a.bias[q];
+    if (ntile == 0) return;
+    const int f0 = fb * 256 + wave * 64;
+
+    // weights: fragment (ft, kb) = rows f0 + ft*16 + (lane & 15), k = kb*32 + 8*(lane >> 4) .. +7; pinned in the accumulator file
+    s16x8 wreg[4][KB];
+    {
+        const bf16_t* Wg = (const bf16_t*)a.W + (int64_t)(f0 + s16) * K + 8 * q4;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wreg[ft][kb]) : "v"(Wg + (int64_t)ft * 16 * K + kb * 32) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int kb = 0; kb < KB; kb += 8)
+                asm volatile("s_waitcnt vmcnt(0)" : "+a"(wreg[ft][kb]), "+a"(wreg[ft][kb + 1]), "+a"(wreg[ft][kb + 2]), "+a"(wreg[ft][kb + 3]),
+                             "+a"(wreg[ft][kb + 4]), "+a"(wreg[ft][kb + 5]), "+a"(wreg[ft][kb + 6]), "+a"(wreg[ft][kb + 7]));
+    }
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint64_t a_base = (uint64_t)(uintptr_t)a.A;
+    const u32x4_t a_rsrc = {(uint32_t)a_base, (uint32_t)(a_base >> 32) & 0xFFFFu, (uint32_t)(a.M * (K * 2)), 0x00020000u};
+    auto fetch_row = [&](uint32_t tile_soff, int buf, int q) {
+        bufl16_lds(a_rsrc, (uint32_t)(((lane ^ ((wave * RPW + q) & 15)) << 4) + q * 1024), tile_soff, lds0 + buf * WS16_TILE_BYTES + (wave * RPW + q) * 1024);
+    };
+    auto row0 = [&](int ti) -> int64_t { return ((int64_t)ti * stride + first) * WS16_RT; };
+
+    // BatchNorm sums over all tiles: [fp] = the 16-lane row's total of feature f0 + fp*32 + ((lane >> 2) & 1)*16 + 4*q4 + (lane & 3)
+    float qs1[2] = {0.f, 0.f}, qs2[2] = {0.f, 0.f};
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * a.ldc * 2), 0x00020000);
+    // after the permlane16 swap a lane owns features foff .. foff + 7 of the 32-feature pair: foff = {0, 16, 8, 24}[q4]
+    const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);
+    const uint32_t c_lane = (uint32_t)(s16 * a.ldc + f0 + foff) * 2;
+    const int d16 = (q4 ^ s16) << 4;
+
+    float t1[8], t2[8];               // sums over the 4 sample tiles of the current feature-tile pair: value o*4 + e
+    // epilogue slot u = 0 .. 2*ST-1 of a finished tile: feature-tile pair fp = u / ST, sample tile st = u % ST
+    auto epi_slot = [&](Ws16Acc& old, int u, uint32_t s_old, const bool (&live)[ST]) {
+        const int fp = u / ST, st = u % ST;
+        uint2 pk[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int ft = 2 * fp + o;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                asm("v_max_f32 %0, 0, %1" : "=v"(v[e]) : "v"(old.t[ft][st][e]));
+                const float w = live[st] ? v[e] : 0.f;
+                if (st == 0) { t1[o * 4 + e] = w; t2[o * 4 + e] = w * w; }
+                else { t1[o * 4 + e] += w; t2[o * 4 + e] = fmaf(w, w, t2[o * 4 + e]); }
+            }
+            pk[o].x = cvt_pk_bf16<false>(v[0], v[1]);
+            pk[o].y = cvt_pk_bf16<false>(v[2], v[3]);
+        }
+        const auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+        const u32x4_t c = {sx[0], sy[0], sx[1], sy[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.ldc + fp * 32) * 2, 0);
+        if (st == ST - 1) {
+            qs1[fp] += row16_fold8(t1, lane);
+            qs2[fp] += row16_fold8(t2, lane);
+        }
+    };
+
+    auto step = [&](Ws16Acc& acc, Ws16Acc& old, int ti, int buf, bool has_next, auto with_epi_tag, int64_t m_old) {
+        constexpr bool WITH_EPI = decltype(with_epi_tag)::value;
+        const uint32_t next_soff = has_next ? (uint32_t)((row0(ti + 1) + wave * RPW) * (K * 2)) : 0xFFF00000u;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const float4 b4 = *(const float4*)(bias_s + f0 + ft * 16 + 4 * q4);
+            const f32x4_t b0 = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int st = 0; st < ST; ++st) acc.t[ft][st] = b0;
+        }
+        const unsigned char* At = smem + buf * WS16_TILE_BYTES + s16 * 1024;
+        const uint32_t s_old = (uint32_t)(m_old * a.ldc * 2);
+        bool all_live[ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) all_live[st] = true;
+        // one fragment per sample tile, re-read for the next k block right behind the 4 MFMAs that consumed it: the read has
+        // the other sample tiles' 8 MFMAs (128 cycles) to return
+        uint4 fa[ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) fa[st] = *(const uint4*)(At + st * 16384 + (0 ^ d16));
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (kb < RPW) fetch_row(next_soff, buf ^ 1, kb);
+#pragma unroll
+            for (int st = 0; st < ST; ++st) {
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    acc.t[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ft][kb], __builtin_bit_cast(s16x8, fa[st]), acc.t[ft][st], 0, 0, 0);
+                if (kb + 1 < KB) fa[st] = *(const uint4*)(At + st * 16384 + ((((kb + 1) * 4) << 4) ^ d16));
+            }
+            if constexpr (WITH_EPI)
+                if (kb >= 6 && kb < 6 + 2 * ST) epi_slot(old, kb - 6, s_old, all_live);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto drain = [&](Ws16Acc& old, int64_t m_old) {
+        const uint32_t s_old = (uint32_t)(m_old * a.ldc * 2);
+        bool live[ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) live[st] = m_old + st * 16 + s16 < a.M;
+#pragma unroll
+        for (int u = 0; u < 2 * ST; ++u) epi_slot(old, u, s_old, live);
+    };
+
+    Ws16Acc accA, accB;
+    {
+        const uint32_t soff0 = (uint32_t)((row0(0) + wave * RPW) * (K * 2));
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) fetch_row(soff0, 0, q);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    step(accA, accB, 0, 0, ntile > 1, std::false_type{}, 0);
+    int ti = 1;
+    while (ti + 1 < ntile) {
+        step(accB, accA, ti, ti & 1, true, std::true_type{}, row0(ti - 1));
+        step(accA, accB, ti + 1, (ti + 1) & 1, ti + 2 < ntile, std::true_type{}, row0(ti));
+        ti += 2;
+    }
+    if (ti < ntile) {
+        step(accB, accA, ti, ti & 1, false, std::true_type{}, row0(ti - 1));
+        drain(accB, row0(ti));
+    } else {
+        drain(accA, row0(ntile - 1));
+    }
+    // the four 16-lane rows (q4) of the wave hold DIFFERENT features: no further reduction.  Lane (q4, s16), pair fp: value
+    // s16 & 7 = o*4 + e  ->  feature f0 + fp*32 + o*16 + 4*q4 + e; lanes s16 < 8 write
+    if (s16 < 8) {
+        const int64_t prow = (int64_t)wkr * 8 + xcd;
+#pragma unroll
+        for (int fp = 0; fp < 2; ++fp) {
+            const int f = f0 + fp * 32 + (s16 >> 2) * 16 + 4 * q4 + (s16 & 3);
+            a.partials[(prow * 2 + 0) * a.F + f] = qs1[fp];
+            a.partials[(prow * 2 + 1) * a.F + f] = qs2[fp];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same structure for the fc DATA gradients whose epilogue applies BatchNorm + ReLU backward of the layer below
 // (EPI_DGRAD_BN; gemm_nt256p.cuh for what that means):  C[m][f] = [r > 0] (ca[f] * (A W^T)[m][f] + cb[f] * r[m][f] + cz[f]),
 // r = the saved activation of the layer below, column sums of C = that layer's bias gradient.  K = 512, F = 512 or 768.
@@ -496,12 +690,16 @@ template <int EPI>
 static inline hipError_t launch_gemm_ws(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
     if (a.K != WS_K || (a.F & 255) || a.F > 768 || a.lda != WS_K) return hipErrorInvalidValue;
     const int nfb = a.F >> 8, nwk = 32 / nfb;
-    const int64_t tiles = (a.M + WS_RT - 1) / WS_RT;
+    const bool m16 = EPI == EPI_FWD && !(a.dbg & 512) && !getenv("CPNATIVE_WS32");
+    const int rt = m16 ? WS16_RT : WS_RT;
+    const int64_t tiles = (a.M + rt - 1) / rt;
     const int64_t workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
 #ifndef WS_WAVES
 #define WS_WAVES 4
 #endif
-    hipLaunchKernelGGL((gemm_ws_kernel<EPI, WS_WAVES>), dim3(256), dim3(64 * WS_WAVES), 0, st, a);
+    // (dbg 512 / $CPNATIVE_WS32: the v_mfma_f32_32x32x16_bf16 form instead of the 16x16x32 one)
+    if (m16) hipLaunchKernelGGL(gemm_ws16_kernel, dim3(256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_ws_kernel<EPI, WS_WAVES>), dim3(256), dim3(64 * WS_WAVES), 0, st, a);
     return hipGetLastError();
 }
