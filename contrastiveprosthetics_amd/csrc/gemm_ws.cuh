@@ -497,6 +497,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 #define WSD_RT 32
 #define WSD_TILE_BYTES (WSD_RT * WS_K * 2)
+#define WSD16_RT 32          // 48-row tiles (as in the forward) spill here: the epilogue holds R and the coefficients as well
 
 __global__ __launch_bounds__(256, 1) void gemm_wsd_bn_kernel(GemmNTArgs a) {
     constexpr int K = WS_K, KB = K / 16, RPW = WSD_RT / 4;
@@ -675,13 +676,191 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd_bn_kernel(GemmNTArgs a) {
     }
 }
 
+// The data-gradient kernel on v_mfma_f32_16x16x32_bf16 (see gemm_ws16_kernel): 32-row tiles = 2 sample tiles of 16, the saved
+// activation read in the 16x16 accumulator layout (lane (q4, s): features ft*16 + 4*q4 .. +3 of row st*16 + s).
+__global__ __launch_bounds__(256, 1) void gemm_wsd16_bn_kernel(GemmNTArgs a) {
+    constexpr int RT = WSD16_RT, TILE_BYTES = RT * WS_K * 2, R_BYTES = RT * 128;          // R: per wave and buffer, rows of 64 features
+    constexpr int K = WS_K, KB = K / 32, RPW = RT / 4, ST = RT / 16;
+    constexpr int R_OFF = 2 * TILE_BYTES, COEF_OFF = R_OFF + 4 * 2 * R_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[COEF_OFF + 3 * 256 * 4];
+    float* coef_s = (float*)(smem + COEF_OFF);                               // [3][256]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, q4 = lane >> 4;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nfb = a.F >> 8;
+    const int nwk = 32 / nfb;
+    const int fb = j % nfb, wkr = j / nfb;
+    const int64_t tiles = (a.M + RT - 1) / RT;
+    const int first = wkr * 8 + xcd, stride = nwk * 8;
+    const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
+    if (ntile == 0) return;
+    for (int q = tid; q < 3 * 256; q += 256) {
+        const int c = q >> 8, f = fb * 256 + (q & 255);
+        coef_s[q] = a.coef[c * a.coef_mod + f % a.coef_mod];
+    }
+    const int f0 = fb * 256 + wave * 64, fl0 = wave * 64;
+
+    s16x8 wreg[4][KB];
+    {
+        const bf16_t* Wg = (const bf16_t*)a.W + (int64_t)(f0 + s16) * K + 8 * q4;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wreg[ft][kb]) : "v"(Wg + (int64_t)ft * 16 * K + kb * 32) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int kb = 0; kb < KB; kb += 8)
+                asm volatile("s_waitcnt vmcnt(0)" : "+a"(wreg[ft][kb]), "+a"(wreg[ft][kb + 1]), "+a"(wreg[ft][kb + 2]), "+a"(wreg[ft][kb + 3]),
+                             "+a"(wreg[ft][kb + 4]), "+a"(wreg[ft][kb + 5]), "+a"(wreg[ft][kb + 6]), "+a"(wreg[ft][kb + 7]));
+    }
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint64_t a_base = (uint64_t)(uintptr_t)a.A, r_base = (uint64_t)(uintptr_t)a.R;
+    const u32x4_t a_rsrc = {(uint32_t)a_base, (uint32_t)(a_base >> 32) & 0xFFFFu, (uint32_t)(a.M * (K * 2)), 0x00020000u};
+    const u32x4_t r_rsrc = {(uint32_t)r_base, (uint32_t)(r_base >> 32) & 0xFFFFu, (uint32_t)(a.M * a.ldr * 2), 0x00020000u};
+    auto fetch_a = [&](uint32_t tile_soff, int buf, int q) {
+        bufl16_lds(a_rsrc, (uint32_t)(((lane ^ ((wave * RPW + q) & 15)) << 4) + q * 1024), tile_soff, lds0 + buf * TILE_BYTES + (wave * RPW + q) * 1024);
+    };
+    const uint32_t r_lane = (uint32_t)((lane >> 3) * a.ldr * 2 + f0 * 2);
+    auto fetch_r = [&](uint32_t tile_soff, int buf, int k) {
+        const int row = 8 * k + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        bufl16_lds(r_rsrc, r_lane + (uint32_t)(8 * k * a.ldr * 2 + lc * 16), tile_soff, lds0 + R_OFF + (wave * 2 + buf) * R_BYTES + k * 1024);
+    };
+    auto row0 = [&](int ti) -> int64_t { return ((int64_t)ti * stride + first) * RT; };
+
+    float qs1[2] = {0.f, 0.f};
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * a.ldc * 2), 0x00020000);
+    const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);
+    const uint32_t c_lane = (uint32_t)(s16 * a.ldc + f0 + foff) * 2;
+    const int d16 = (q4 ^ s16) << 4;
+
+    float t1[8];
+    // epilogue slot u = 0 .. 2*ST-1 of a finished tile: feature-tile pair fp = u / ST, sample tile st = u % ST
+    auto epi_slot = [&](f32x4_t (&old)[4][ST], const unsigned char* Rw, int u, uint32_t s_old, const bool (&live)[ST]) {
+        const int fp = u / ST, st = u % ST;
+        const int row = st * 16 + s16;
+        const int rsw = (row >> 1) & 7;
+        uint2 pk[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int ft = 2 * fp + o;
+            const uint2 rr = *(const uint2*)(Rw + row * 128 + (((ft * 2 + (q4 >> 1)) ^ rsw) << 4) + 8 * (q4 & 1));
+            const int fl = fl0 + ft * 16 + 4 * q4;
+            const float4 ca = *(const float4*)(coef_s + fl), cb = *(const float4*)(coef_s + 256 + fl), cz = *(const float4*)(coef_s + 512 + fl);
+            const float r0 = __uint_as_float(rr.x << 16), r1 = __uint_as_float(rr.x & 0xffff0000u);
+            const float r2 = __uint_as_float(rr.y << 16), r3 = __uint_as_float(rr.y & 0xffff0000u);
+            const float y0 = r0 > 0.f ? fmaf(ca.x, old[ft][st][0], fmaf(cb.x, r0, cz.x)) : 0.f;
+            const float y1 = r1 > 0.f ? fmaf(ca.y, old[ft][st][1], fmaf(cb.y, r1, cz.y)) : 0.f;
+            const float y2 = r2 > 0.f ? fmaf(ca.z, old[ft][st][2], fmaf(cb.z, r2, cz.z)) : 0.f;
+            const float y3 = r3 > 0.f ? fmaf(ca.w, old[ft][st][3], fmaf(cb.w, r3, cz.w)) : 0.f;
+            pk[o].x = cvt_pk_bf16<false>(y0, y1);
+            pk[o].y = cvt_pk_bf16<false>(y2, y3);
+            // column sums of the values as stored (the layer's bias gradient); rows past the end do not count
+            float g[4] = {__uint_as_float(pk[o].x << 16), __uint_as_float(pk[o].x & 0xffff0000u),
+                          __uint_as_float(pk[o].y << 16), __uint_as_float(pk[o].y & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float w = live[st] ? g[e] : 0.f;
+                if (st == 0) t1[o * 4 + e] = w; else t1[o * 4 + e] += w;
+            }
+        }
+        const auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+        const u32x4_t c = {sx[0], sy[0], sx[1], sy[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.ldc + fp * 32) * 2, 0);
+        if (st == ST - 1) qs1[fp] += row16_fold8(t1, lane);
+    };
+
+    auto step = [&](f32x4_t (&acc)[4][ST], f32x4_t (&old)[4][ST], int ti, int buf, bool has_next, auto with_epi_tag, int64_t m_old) {
+        constexpr bool WITH_EPI = decltype(with_epi_tag)::value;
+        const uint32_t next_soff = has_next ? (uint32_t)((row0(ti + 1) + wave * RPW) * (K * 2)) : 0xFFF00000u;
+        const uint32_t r_soff = (uint32_t)(row0(ti) * a.ldr * 2);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int st = 0; st < ST; ++st) acc[ft][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const unsigned char* At = smem + buf * TILE_BYTES + s16 * 1024;
+        const unsigned char* Rw = smem + R_OFF + (wave * 2 + (buf ^ 1)) * R_BYTES;
+        const uint32_t s_old = (uint32_t)(m_old * a.ldc * 2);
+        bool all_live[ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) all_live[st] = true;
+        uint4 fa[ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) fa[st] = *(const uint4*)(At + st * 16384 + (0 ^ d16));
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (kb < RPW) fetch_a(next_soff, buf ^ 1, kb);
+            if ((kb & 1) == 0 && (kb >> 1) < RT / 8) fetch_r(r_soff, buf, kb >> 1);
+#pragma unroll
+            for (int st = 0; st < ST; ++st) {
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ft][kb], __builtin_bit_cast(s16x8, fa[st]), acc[ft][st], 0, 0, 0);
+                if (kb + 1 < KB) fa[st] = *(const uint4*)(At + st * 16384 + ((((kb + 1) * 4) << 4) ^ d16));
+            }
+            if constexpr (WITH_EPI)
+                if (kb >= 4 && kb < 4 + 2 * 2 * ST && (kb & 1) == 0) epi_slot(old, Rw, (kb - 4) >> 1, s_old, all_live);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto drain = [&](f32x4_t (&old)[4][ST], int buf, int64_t m_old) {
+        const unsigned char* Rw = smem + R_OFF + (wave * 2 + buf) * R_BYTES;
+        const uint32_t s_old = (uint32_t)(m_old * a.ldc * 2);
+        bool live[ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) live[st] = m_old + st * 16 + s16 < a.M;
+#pragma unroll
+        for (int u = 0; u < 2 * ST; ++u) epi_slot(old, Rw, u, s_old, live);
+    };
+
+    f32x4_t accA[4][ST], accB[4][ST];
+    {
+        const uint32_t soff0 = (uint32_t)((row0(0) + wave * RPW) * (K * 2));
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) fetch_a(soff0, 0, q);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    step(accA, accB, 0, 0, ntile > 1, std::false_type{}, 0);
+    int ti = 1;
+    while (ti + 1 < ntile) {
+        step(accB, accA, ti, ti & 1, true, std::true_type{}, row0(ti - 1));
+        step(accA, accB, ti + 1, (ti + 1) & 1, ti + 2 < ntile, std::true_type{}, row0(ti));
+        ti += 2;
+    }
+    if (ti < ntile) {
+        step(accB, accA, ti, ti & 1, false, std::true_type{}, row0(ti - 1));
+        drain(accB, ti & 1, row0(ti));
+    } else {
+        drain(accA, (ntile - 1) & 1, row0(ntile - 1));
+    }
+    if (s16 < 8) {
+        const int64_t prow = (int64_t)wkr * 8 + xcd;
+#pragma unroll
+        for (int fp = 0; fp < 2; ++fp) {
+            const int f = f0 + fp * 32 + (s16 >> 2) * 16 + 4 * q4 + (s16 & 3);
+            a.partials[prow * a.F + f] = qs1[fp];                            // bias gradient of the layer below: rows of F
+        }
+    }
+}
+
 static inline hipError_t launch_gemm_wsd_bn(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
     if (a.K != WS_K || (a.F & 255) || a.F > 768 || a.lda != WS_K || !a.R || !a.coef) return hipErrorInvalidValue;
-    const int nfb = a.F >> 8, nwk = 32 / nfb;
-    const int64_t tiles = (a.M + WSD_RT - 1) / WSD_RT;
+    const bool m16 = !(a.dbg & 512) && !getenv("CPNATIVE_WS32") && !getenv("CPNATIVE_WSD32");          // (the 32x32x16 form)
+    const int nfb = a.F >> 8, nwk = 32 / nfb, rt = m16 ? WSD16_RT : WSD_RT;
+    const int64_t tiles = (a.M + rt - 1) / rt;
     const int64_t workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
-    hipLaunchKernelGGL(gemm_wsd_bn_kernel, dim3(256), dim3(256), 0, st, a);
+    if (m16) hipLaunchKernelGGL(gemm_wsd16_bn_kernel, dim3(256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_wsd_bn_kernel, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+for i in 1 2; do
+for L in default WSD32 WS32; do
+  unset CPNATIVE_WS32 CPNATIVE_WSD32
+  [ $L = WSD32 ] && export CPNATIVE_WSD32=1
+  [ $L = WS32 ] && export CPNATIVE_WS32=1
+  python bench.py --no_cpu_baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+pk=d['roofline']['per_kernel']
+sp=d.get('steps_spread', {})
+print('%-10s %.3f ms/step (median %.3f, min %.3f)  ' % ('$L', d['ms_per_step'], sp.get('median_ms', 0), sp.get('min_ms', 0)) + '  '.join('%s %.1f' % (k, v['avg_us']) for k, v in pk.items()))"
+done
+done
