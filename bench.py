@@ -41,13 +41,29 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 # profiler kind -> (the ONE kernel it times, as rocprofv3 names it; fc layer indices it runs on when dropout is on / off)
 # ({dyn} = the tile schedule, include/cpnative.h cp_set_tile_schedule: "false" static, "true" dynamic)
 GEMM_KERNELS = {
-    "fc_fwd_ws": "gemm_ws_kernel<0, 4>",                  # weight-stationary forward, fc2..fc7 (K = 512), static schedule
+    "fc_fwd_ws": "gemm_ws16_kernel",                      # weight-stationary forward, fc2..fc7 (K = 512), static schedule
     "fc_fwd": "gemm_nt256p_kernel<0, 4, {dyn}>",          # persistent, bias + ReLU + BN sums in the epilogue: fc1 (K = 768)
     "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
-    "fc_dgrad_bn": "gemm_nt256p_kernel<3, 4, {dyn}>",     # persistent, + BN/ReLU backward of the layer below against the saved activation
-    "fc_dgrad_stats": "gemm_nt256p_kernel<4, 4, {dyn}>",  # persistent, behind a dropout: mask + BN-backward sums against the saved activation
+    "fc_dgrad_bn": "gemm_wsd16_kernel<0>",                # weight-stationary, + BN/ReLU backward of the layer below against the saved activation
+    "fc_dgrad_stats": "gemm_wsd16_kernel<1>",             # weight-stationary, behind a dropout: mask + BN-backward sums against the saved activation
     "fc_wgrad": "gemm_tn256_kernel",
 }
+
+
+def gemm_symbol(kind: str, dyn: str) -> str:
+    """The kernel symbol a GEMM kind runs as under this process's switches (csrc/gemm_ws.cuh launchers): the
+    16x16x32 weight-stationary kernels by default, their 32x32x16 forms or the tile-staged kernels on request."""
+    env = os.environ
+    if kind == "fc_fwd_ws" and env.get("CPNATIVE_WS32"):
+        return "gemm_ws_kernel<0, 4>"
+    if kind == "fc_dgrad_bn":
+        if env.get("CPNATIVE_NO_WSD"):
+            return "gemm_nt256p_kernel<3, 4, %s>" % dyn
+        if env.get("CPNATIVE_WS32") or env.get("CPNATIVE_WSD32"):
+            return "gemm_wsd_bn_kernel"
+    if kind == "fc_dgrad_stats" and (env.get("CPNATIVE_NO_WSD") or env.get("CPNATIVE_NO_WSD_ST")):
+        return "gemm_nt256p_kernel<4, 4, %s>" % dyn
+    return GEMM_KERNELS[kind].format(dyn=dyn)
 
 
 def gemm_model(kind: str, n: int, es: int, dropout: bool):
@@ -285,7 +301,7 @@ def main():
         mpath = os.path.join(ROOT, "profiles", "r02_mfma.json")
         if args.dtype == "bf16" and B == 4096 and os.path.exists(mpath):
             for k, v in json.load(open(mpath))["kernels"].items():
-                if GEMM_KERNELS[dom].format(dyn="true" if eng.lib.cp_get_tile_schedule() else "false") in k:
+                if gemm_symbol(dom, "true" if eng.lib.cp_get_tile_schedule() else "false") in k:
                     mfma_busy = v["mfma_busy_frac"]
         avg_s = ms / launches / 1e3
         byts, flops = gemm_model(dom, N, es, args.dp_emg > 0)
@@ -296,7 +312,7 @@ def main():
         # separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction); null if not profiled
         traffic = None
         dyn = "true" if eng.lib.cp_get_tile_schedule() else "false"
-        kname = GEMM_KERNELS[dom].format(dyn=dyn)
+        kname = gemm_symbol(dom, dyn)
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if args.dtype == "bf16" and B == 4096 and os.path.exists(tpath):
             for k, v in json.load(open(tpath))["kernels"].items():
@@ -307,7 +323,7 @@ def main():
             if k in prof and prof[k][1] > 0:
                 kb, kf = gemm_model(k, N, es, args.dp_emg > 0)
                 ks_ = prof[k][0] / prof[k][1] / 1e3
-                per_kernel[k] = dict(symbol=GEMM_KERNELS[k].format(dyn=dyn), launches=prof[k][1], avg_us=ks_ * 1e6, algorithmic_bytes=kb,
+                per_kernel[k] = dict(symbol=gemm_symbol(k, dyn), launches=prof[k][1], avg_us=ks_ * 1e6, algorithmic_bytes=kb,
                                      gbs=kb / ks_ / 1e9, hbm_frac=kb / ks_ / 1e9 / HBM_PEAK_GBS, tflops=kf / ks_ / 1e12)
         bound = "hbm" if byts / (HBM_PEAK_GBS * 1e9) >= flops / (mfma_peak * 1e12) else "mfma"
         roof = dict(bound=bound, kernel=dom, kernel_symbol=kname, launches=launches, avg_us=avg_s * 1e6,

@@ -298,8 +298,9 @@ static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int
             return launch_gemm_ws<EPI_FWD>(a, st, stat_rows);
         if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows, dyn);
         // BatchNorm + ReLU backward in the data-gradient epilogue, static schedule: the weight-stationary form (gemm_ws.cuh)
-        if (EPI == EPI_DGRAD && a.R != nullptr && a.coef != nullptr && a.K == WS_K && a.lda == WS_K && !dyn && !(a.dbg & (16 | 256)) &&
-            !getenv("CPNATIVE_NO_WS") && !getenv("CPNATIVE_NO_WSD"))
+        // (and, behind a dropout, the mask + BatchNorm-backward sums; $CPNATIVE_NO_WSD_ST keeps that one on the tile-staged kernel)
+        if (EPI == EPI_DGRAD && a.R != nullptr && (a.coef != nullptr || !getenv("CPNATIVE_NO_WSD_ST")) && a.K == WS_K && a.lda == WS_K && !dyn &&
+            !(a.dbg & (16 | 256)) && !getenv("CPNATIVE_NO_WS") && !getenv("CPNATIVE_NO_WSD"))
             return launch_gemm_wsd_bn(a, st, stat_rows);
         if (EPI == EPI_DGRAD && a.R != nullptr && !(a.dbg & 16) && !getenv("CPNATIVE_STAGED_R_EPILOGUE")) {
             // the persistent kernel's R epilogues: BN + ReLU backward of the layer below (coef), or dropout + BN-backward sums

@@ -678,7 +678,12 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd_bn_kernel(GemmNTArgs a) {
 
 // The data-gradient kernel on v_mfma_f32_16x16x32_bf16 (see gemm_ws16_kernel): 32-row tiles = 2 sample tiles of 16, the saved
 // activation read in the 16x16 accumulator layout (lane (q4, s): features ft*16 + 4*q4 .. +3 of row st*16 + s).
-__global__ __launch_bounds__(256, 1) void gemm_wsd16_bn_kernel(GemmNTArgs a) {
+// MODE 0 (EPI_DGRAD_BN): BatchNorm + ReLU backward of the layer below in the epilogue (coef), column sums of the result = its bias
+// gradient.  MODE 1 (EPI_DGRAD_ST, behind a dropout): the dropout mask of the layer's input (the forward pass's hash) and the two
+// BatchNorm-backward sums of the masked gradient against the saved activation, partial rows [2][F].
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void gemm_wsd16_kernel(GemmNTArgs a) {
+    constexpr bool STATS = MODE == 1;
     constexpr int RT = WSD16_RT, TILE_BYTES = RT * WS_K * 2, R_BYTES = RT * 128;          // R: per wave and buffer, rows of 64 features
     constexpr int K = WS_K, KB = K / 32, RPW = RT / 4, ST = RT / 16;
     constexpr int R_OFF = 2 * TILE_BYTES, COEF_OFF = R_OFF + 4 * 2 * R_BYTES;
@@ -696,10 +701,12 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_bn_kernel(GemmNTArgs a) {
     const int first = wkr * 8 + xcd, stride = nwk * 8;
     const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
     if (ntile == 0) return;
-    for (int q = tid; q < 3 * 256; q += 256) {
-        const int c = q >> 8, f = fb * 256 + (q & 255);
-        coef_s[q] = a.coef[c * a.coef_mod + f % a.coef_mod];
-    }
+    if constexpr (!STATS)
+        for (int q = tid; q < 3 * 256; q += 256) {
+            const int c = q >> 8, f = fb * 256 + (q & 255);
+            coef_s[q] = a.coef[c * a.coef_mod + f % a.coef_mod];
+        }
+    const uint32_t dkey = (STATS && a.dp_thresh != 0) ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
     const int f0 = fb * 256 + wave * 64, fl0 = wave * 64;
 
     s16x8 wreg[4][KB];
@@ -734,15 +741,15 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_bn_kernel(GemmNTArgs a) {
     };
     auto row0 = [&](int ti) -> int64_t { return ((int64_t)ti * stride + first) * RT; };
 
-    float qs1[2] = {0.f, 0.f};
+    float qs1[2] = {0.f, 0.f}, qs2[2] = {0.f, 0.f};
     const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * a.ldc * 2), 0x00020000);
     const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);
     const uint32_t c_lane = (uint32_t)(s16 * a.ldc + f0 + foff) * 2;
     const int d16 = (q4 ^ s16) << 4;
 
-    float t1[8];
+    float t1[8], t2[8];
     // epilogue slot u = 0 .. 2*ST-1 of a finished tile: feature-tile pair fp = u / ST, sample tile st = u % ST
-    auto epi_slot = [&](f32x4_t (&old)[4][ST], const unsigned char* Rw, int u, uint32_t s_old, const bool (&live)[ST]) {
+    auto epi_slot = [&](f32x4_t (&old)[4][ST], const unsigned char* Rw, int u, uint32_t s_old, const bool (&live)[ST], int64_t m_old) {
         const int fp = u / ST, st = u % ST;
         const int row = st * 16 + s16;
         const int rsw = (row >> 1) & 7;
@@ -751,30 +758,49 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_bn_kernel(GemmNTArgs a) {
         for (int o = 0; o < 2; ++o) {
             const int ft = 2 * fp + o;
             const uint2 rr = *(const uint2*)(Rw + row * 128 + (((ft * 2 + (q4 >> 1)) ^ rsw) << 4) + 8 * (q4 & 1));
-            const int fl = fl0 + ft * 16 + 4 * q4;
-            const float4 ca = *(const float4*)(coef_s + fl), cb = *(const float4*)(coef_s + 256 + fl), cz = *(const float4*)(coef_s + 512 + fl);
             const float r0 = __uint_as_float(rr.x << 16), r1 = __uint_as_float(rr.x & 0xffff0000u);
             const float r2 = __uint_as_float(rr.y << 16), r3 = __uint_as_float(rr.y & 0xffff0000u);
-            const float y0 = r0 > 0.f ? fmaf(ca.x, old[ft][st][0], fmaf(cb.x, r0, cz.x)) : 0.f;
-            const float y1 = r1 > 0.f ? fmaf(ca.y, old[ft][st][1], fmaf(cb.y, r1, cz.y)) : 0.f;
-            const float y2 = r2 > 0.f ? fmaf(ca.z, old[ft][st][2], fmaf(cb.z, r2, cz.z)) : 0.f;
-            const float y3 = r3 > 0.f ? fmaf(ca.w, old[ft][st][3], fmaf(cb.w, r3, cz.w)) : 0.f;
+            float y0 = old[ft][st][0], y1 = old[ft][st][1], y2 = old[ft][st][2], y3 = old[ft][st][3];
+            if constexpr (!STATS) {
+                const int fl = fl0 + ft * 16 + 4 * q4;
+                const float4 ca = *(const float4*)(coef_s + fl), cb = *(const float4*)(coef_s + 256 + fl), cz = *(const float4*)(coef_s + 512 + fl);
+                y0 = r0 > 0.f ? fmaf(ca.x, y0, fmaf(cb.x, r0, cz.x)) : 0.f;
+                y1 = r1 > 0.f ? fmaf(ca.y, y1, fmaf(cb.y, r1, cz.y)) : 0.f;
+                y2 = r2 > 0.f ? fmaf(ca.z, y2, fmaf(cb.z, r2, cz.z)) : 0.f;
+                y3 = r3 > 0.f ? fmaf(ca.w, y3, fmaf(cb.w, r3, cz.w)) : 0.f;
+            } else if (a.dp_thresh != 0) {
+                const uint32_t col = (uint32_t)(f0 + ft * 16 + 4 * q4);            // column of y0 in the output row (even)
+                const uint32_t m = (uint32_t)(m_old + row);
+                const uint32_t p0 = dropout_pair(dkey, m, (uint32_t)a.ldc, col);
+                const uint32_t p1 = dropout_pair(dkey, m, (uint32_t)a.ldc, col + 2);
+                y0 *= dropout_scale(p0, 0, a.dp_thresh, a.dp_inv_keep);
+                y1 *= dropout_scale(p0, 1, a.dp_thresh, a.dp_inv_keep);
+                y2 *= dropout_scale(p1, 0, a.dp_thresh, a.dp_inv_keep);
+                y3 *= dropout_scale(p1, 1, a.dp_thresh, a.dp_inv_keep);
+            }
             pk[o].x = cvt_pk_bf16<false>(y0, y1);
             pk[o].y = cvt_pk_bf16<false>(y2, y3);
-            // column sums of the values as stored (the layer's bias gradient); rows past the end do not count
+            // column sums of the values as stored (MODE 0: the layer's bias gradient); rows past the end do not count
             float g[4] = {__uint_as_float(pk[o].x << 16), __uint_as_float(pk[o].x & 0xffff0000u),
                           __uint_as_float(pk[o].y << 16), __uint_as_float(pk[o].y & 0xffff0000u)};
+            const float rv[4] = {r0, r1, r2, r3};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float w = live[st] ? g[e] : 0.f;
                 if (st == 0) t1[o * 4 + e] = w; else t1[o * 4 + e] += w;
+                if constexpr (STATS) {
+                    if (st == 0) t2[o * 4 + e] = w * rv[e]; else t2[o * 4 + e] = fmaf(w, rv[e], t2[o * 4 + e]);
+                }
             }
         }
         const auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
         const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
         const u32x4_t c = {sx[0], sy[0], sx[1], sy[1]};
         __builtin_amdgcn_raw_buffer_store_b128(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.ldc + fp * 32) * 2, 0);
-        if (st == ST - 1) qs1[fp] += row16_fold8(t1, lane);
+        if (st == ST - 1) {
+            qs1[fp] += row16_fold8(t1, lane);
+            if constexpr (STATS) qs2[fp] += row16_fold8(t2, lane);
+        }
     };
 
     auto step = [&](f32x4_t (&acc)[4][ST], f32x4_t (&old)[4][ST], int ti, int buf, bool has_next, auto with_epi_tag, int64_t m_old) {
@@ -806,7 +832,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_bn_kernel(GemmNTArgs a) {
                 if (kb + 1 < KB) fa[st] = *(const uint4*)(At + st * 16384 + ((((kb + 1) * 4) << 4) ^ d16));
             }
             if constexpr (WITH_EPI)
-                if (kb >= 4 && kb < 4 + 2 * 2 * ST && (kb & 1) == 0) epi_slot(old, Rw, (kb - 4) >> 1, s_old, all_live);
+                if (kb >= 4 && kb < 4 + 2 * 2 * ST && (kb & 1) == 0) epi_slot(old, Rw, (kb - 4) >> 1, s_old, all_live, m_old);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -818,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_bn_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int st = 0; st < ST; ++st) live[st] = m_old + st * 16 + s16 < a.M;
 #pragma unroll
-        for (int u = 0; u < 2 * ST; ++u) epi_slot(old, Rw, u, s_old, live);
+        for (int u = 0; u < 2 * ST; ++u) epi_slot(old, Rw, u, s_old, live, m_old);
     };
 
     f32x4_t accA[4][ST], accB[4][ST];
@@ -847,19 +873,32 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_bn_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int fp = 0; fp < 2; ++fp) {
             const int f = f0 + fp * 32 + (s16 >> 2) * 16 + 4 * q4 + (s16 & 3);
-            a.partials[prow * a.F + f] = qs1[fp];                            // bias gradient of the layer below: rows of F
+            if constexpr (STATS) {
+                a.partials[(prow * 2 + 0) * a.F + f] = qs1[fp];                  // rows of [2][F]
+                a.partials[(prow * 2 + 1) * a.F + f] = qs2[fp];
+            } else {
+                a.partials[prow * a.F + f] = qs1[fp];                            // bias gradient of the layer below: rows of F
+            }
         }
     }
 }
 
 static inline hipError_t launch_gemm_wsd_bn(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
-    if (a.K != WS_K || (a.F & 255) || a.F > 768 || a.lda != WS_K || !a.R || !a.coef) return hipErrorInvalidValue;
+    if (a.K != WS_K || (a.F & 255) || a.F > 768 || a.lda != WS_K || !a.R) return hipErrorInvalidValue;
+    if (!a.coef) {
+        // behind a dropout: mask + BatchNorm-backward sums (16x16x32 form only)
+        const int nwk_ = 32 / (a.F >> 8);
+        const int64_t tiles_ = (a.M + WSD16_RT - 1) / WSD16_RT, workers_ = (int64_t)nwk_ * 8;
+        if (stat_rows) *stat_rows = (int)(tiles_ < workers_ ? tiles_ : workers_);
+        hipLaunchKernelGGL(gemm_wsd16_kernel<1>, dim3(256), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     const bool m16 = !(a.dbg & 512) && !getenv("CPNATIVE_WS32") && !getenv("CPNATIVE_WSD32");          // (the 32x32x16 form)
     const int nfb = a.F >> 8, nwk = 32 / nfb, rt = m16 ? WSD16_RT : WSD_RT;
     const int64_t tiles = (a.M + rt - 1) / rt;
     const int64_t workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
-    if (m16) hipLaunchKernelGGL(gemm_wsd16_bn_kernel, dim3(256), dim3(256), 0, st, a);
+    if (m16) hipLaunchKernelGGL(gemm_wsd16_kernel<0>, dim3(256), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm_wsd_bn_kernel, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }

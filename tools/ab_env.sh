@@ -1,9 +1,11 @@
+# alternating runs of bench.py on one box under different kernel switches: LEGS="default NO_WSD_ST" bash tools/ab_env.sh
 cd $GRAFT_REPO_ROOT
 for i in 1 2; do
-for L in default WSD32 WS32; do
-  unset CPNATIVE_WS32 CPNATIVE_WSD32
+for L in ${LEGS:-default WSD32 WS32}; do
+  unset CPNATIVE_WS32 CPNATIVE_WSD32 CPNATIVE_NO_WSD_ST
   [ $L = WSD32 ] && export CPNATIVE_WSD32=1
   [ $L = WS32 ] && export CPNATIVE_WS32=1
+  [ $L = NO_WSD_ST ] && export CPNATIVE_NO_WSD_ST=1
   python bench.py --no_cpu_baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

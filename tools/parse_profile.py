@@ -108,11 +108,12 @@ def main():
             g = gui[k][0] / max(gui[k][1], 1) if k in gui else 0.0
             if b <= 0:
                 continue
-            out[k] = dict(launches=int(n), mfma_busy_cycles_per_launch=b, mfma_instructions_per_launch=b / 32.0,
+            per = 16.0 if ("gemm_ws16" in k or "gemm_wsd16" in k) else 32.0          # the 16x16x32 kernels: half the passes
+            out[k] = dict(launches=int(n), mfma_busy_cycles_per_launch=b, mfma_instructions_per_launch=b / per,
                           gui_active_per_launch=g, sq_busy_cycles_per_launch=sq[k][0] / max(sq[k][1], 1) if k in sq else None,
                           mfma_busy_frac=(b / ((g / 8.0) * 1024.0)) if g > 0 else None)
         json.dump(dict(note="SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 1024 SIMDs) per launch; busy / 32 = MFMA instructions "
-                            "(v_mfma_f32_32x32x16_bf16)", kernels=out), open(sys.argv[3], "w"), indent=1)
+                            "(v_mfma_f32_32x32x16_bf16; busy / 16 for the v_mfma_f32_16x16x32_bf16 kernels gemm_ws16 / gemm_wsd16)", kernels=out), open(sys.argv[3], "w"), indent=1)
         for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"])[:8]:
             print("%-60s busy frac %s  MFMAs/launch %.3g" % (k[:60], "%.3f" % v["mfma_busy_frac"] if v["mfma_busy_frac"] else "n/a",
                                                               v["mfma_instructions_per_launch"]))
