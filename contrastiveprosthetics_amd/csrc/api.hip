@@ -982,6 +982,21 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[6]);
             CKL("colsum_finalize_kernel(fc7, fused)");
             bn_done = true;
+        } else if (fuse_ok && drop && sizeof(T) == 2 && !getenv("CPNATIVE_NO_PROJ_FUSED")) {
+            // behind fc7's dropout: the rank-16 product is computed twice (gemm_ws.cuh, proj_dgrad_kernel) -- once for the
+            // BatchNorm-backward sums, once more with fc7's BN + ReLU backward applied -- instead of being written out for a
+            // separate bn_relu_bwd pass
+            CK(launch_proj_dgrad<0>(a, st, &drows));
+            int nr = drows;
+            const float* pp = pre(nr, 2 * 512);
+            if (int e = bwd_finalize(pp, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
+            a.coef = coef; a.coef_mod = 512;
+            CK(launch_proj_dgrad<1>(a, st, &drows));
+            nr = drows;
+            pp = pre(nr, 512);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[6]);
+            CKL("colsum_finalize_kernel(fc7, projection)");
+            bn_done = true;
         } else {
             CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
             if (drop) stat_rows = drows;             // partial rows of BN-backward sums written by this launch

@@ -883,6 +883,181 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_kernel(GemmNTArgs a) {
     }
 }
 
+// ---- the projection's data gradient (K = 16 live columns of dz, F = 512) behind fc7's dropout ---------------------------------
+// g = mask * (dz W) is a rank-16 product: cheap enough to compute TWICE instead of writing it out and reading it back for the
+// BatchNorm + ReLU backward pass (172 MB each way + the pass's own launch).  PASS 0: the two BatchNorm-backward sums of g against the
+// saved activation R, nothing stored (reads R once).  PASS 1, after the coefficients are final: recompute g, apply
+// r > 0 ? ca*g + cb*r + cz : 0, store, column sums of the result (= fc7's bias gradient).  One v_mfma_f32_16x16x16_bf16 per 16 x 16
+// outputs, its operands straight from global memory (8 bytes per lane); a wave owns 64 features of a 32-row tile, fetches its R sub-tile
+// by LDS-DMA one tile ahead and never meets the other waves (no barrier in the loop).  Partial rows as gemm_wsd16_kernel writes them.
+#define PROJ_RT 32
+template <int PASS>
+__global__ __launch_bounds__(256, 2) void proj_dgrad_kernel(GemmNTArgs a) {
+    constexpr int RT = PROJ_RT, ST = RT / 16, R_BYTES = RT * 128;
+    constexpr int COEF_OFF = 4 * 2 * R_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[COEF_OFF + 3 * 256 * 4];
+    float* coef_s = (float*)(smem + COEF_OFF);                               // [3][256]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, q4 = lane >> 4;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nfb = a.F >> 8;
+    const int nwk = (gridDim.x >> 3) / nfb;
+    const int fb = j % nfb, wkr = j / nfb;
+    const int64_t tiles = (a.M + RT - 1) / RT;
+    const int first = wkr * 8 + xcd, stride = nwk * 8;
+    const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
+    if (ntile == 0) return;
+    if constexpr (PASS == 1) {
+        for (int q = tid; q < 3 * 256; q += 256) {
+            const int c = q >> 8, f = fb * 256 + (q & 255);
+            coef_s[q] = a.coef[c * a.coef_mod + f % a.coef_mod];
+        }
+        __syncthreads();
+    }
+    const int f0 = fb * 256 + wave * 64, fl0 = wave * 64;
+    const uint32_t dkey = a.dp_thresh != 0 ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
+
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    s16x4_t wfrag[4];                                                        // W[f0 + ft*16 + s16][4*q4 .. +3]
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) wfrag[ft] = *(const s16x4_t*)((const bf16_t*)a.W + (int64_t)(f0 + ft * 16 + s16) * a.K + 4 * q4);
+
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const uint64_t r_base = (uint64_t)(uintptr_t)a.R;
+    const u32x4_t r_rsrc = {(uint32_t)r_base, (uint32_t)(r_base >> 32) & 0xFFFFu, (uint32_t)(a.M * a.ldr * 2), 0x00020000u};
+    const uint32_t r_lane = (uint32_t)((lane >> 3) * a.ldr * 2 + f0 * 2);
+    auto fetch_r = [&](int64_t m0, int buf) {
+#pragma unroll
+        for (int k = 0; k < RT / 8; ++k) {
+            const int row = 8 * k + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            // (the whole offset in the per-lane part: the bounds check that zeroes the rows past the end is on it)
+            bufl16_lds(r_rsrc, (uint32_t)(m0 * a.ldr * 2) + r_lane + (uint32_t)(8 * k * a.ldr * 2 + lc * 16), 0u, lds0 + (wave * 2 + buf) * R_BYTES + k * 1024);
+        }
+    };
+    auto row0 = [&](int ti) -> int64_t { return ((int64_t)ti * stride + first) * RT; };
+    auto load_dz = [&](int64_t m0, s16x4_t (&d)[ST]) {
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+            int64_t m = m0 + st * 16 + s16;
+            if (m >= a.M) m = a.M - 1;                                       // (those rows are masked out of the sums and never stored)
+            d[st] = *(const s16x4_t*)((const bf16_t*)a.A + m * a.lda + 4 * q4);
+        }
+    };
+
+    float qs1[2] = {0.f, 0.f}, qs2[2] = {0.f, 0.f};
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * a.ldc * 2), 0x00020000);
+    const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);
+    const uint32_t c_lane = (uint32_t)(s16 * a.ldc + f0 + foff) * 2;
+
+    s16x4_t dzf[ST], dzn[ST];
+    fetch_r(row0(0), 0);
+    load_dz(row0(0), dzf);
+    for (int ti = 0; ti < ntile; ++ti) {
+        const int buf = ti & 1;
+        const int64_t m0 = row0(ti);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this tile's R sub-tile has landed (own DMA only)
+        if (ti + 1 < ntile) { fetch_r(row0(ti + 1), buf ^ 1); load_dz(row0(ti + 1), dzn); }
+        f32x4_t acc[4][ST];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int st = 0; st < ST; ++st)
+                acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wfrag[ft], dzf[st], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const unsigned char* Rw = smem + (wave * 2 + buf) * R_BYTES;
+        const uint32_t s_out = (uint32_t)(m0 * a.ldc * 2);
+        float t1[8], t2[8];
+#pragma unroll
+        for (int u = 0; u < 2 * ST; ++u) {
+            const int fp = u / ST, st = u % ST;
+            const int row = st * 16 + s16;
+            const bool live = m0 + row < a.M;
+            const int rsw = (row >> 1) & 7;
+            uint2 pk[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int ft = 2 * fp + o;
+                const uint2 rr = *(const uint2*)(Rw + row * 128 + (((ft * 2 + (q4 >> 1)) ^ rsw) << 4) + 8 * (q4 & 1));
+                const float r0 = __uint_as_float(rr.x << 16), r1 = __uint_as_float(rr.x & 0xffff0000u);
+                const float r2 = __uint_as_float(rr.y << 16), r3 = __uint_as_float(rr.y & 0xffff0000u);
+                float y0 = acc[ft][st][0], y1 = acc[ft][st][1], y2 = acc[ft][st][2], y3 = acc[ft][st][3];
+                if (a.dp_thresh != 0) {
+                    const uint32_t col = (uint32_t)(f0 + ft * 16 + 4 * q4);
+                    const uint32_t m = (uint32_t)(m0 + row);
+                    const uint32_t p0 = dropout_pair(dkey, m, (uint32_t)a.ldc, col);
+                    const uint32_t p1 = dropout_pair(dkey, m, (uint32_t)a.ldc, col + 2);
+                    y0 *= dropout_scale(p0, 0, a.dp_thresh, a.dp_inv_keep);
+                    y1 *= dropout_scale(p0, 1, a.dp_thresh, a.dp_inv_keep);
+                    y2 *= dropout_scale(p1, 0, a.dp_thresh, a.dp_inv_keep);
+                    y3 *= dropout_scale(p1, 1, a.dp_thresh, a.dp_inv_keep);
+                }
+                // the masked gradient as the two-kernel path stores it (bf16), so both orders see the same numbers
+                const uint32_t gx = cvt_pk_bf16<false>(y0, y1), gy = cvt_pk_bf16<false>(y2, y3);
+                float g[4] = {__uint_as_float(gx << 16), __uint_as_float(gx & 0xffff0000u), __uint_as_float(gy << 16), __uint_as_float(gy & 0xffff0000u)};
+                const float rv[4] = {r0, r1, r2, r3};
+                if constexpr (PASS == 1) {
+                    const int fl = fl0 + ft * 16 + 4 * q4;
+                    const float4 ca = *(const float4*)(coef_s + fl), cb = *(const float4*)(coef_s + 256 + fl), cz = *(const float4*)(coef_s + 512 + fl);
+                    g[0] = r0 > 0.f ? fmaf(ca.x, g[0], fmaf(cb.x, r0, cz.x)) : 0.f;
+                    g[1] = r1 > 0.f ? fmaf(ca.y, g[1], fmaf(cb.y, r1, cz.y)) : 0.f;
+                    g[2] = r2 > 0.f ? fmaf(ca.z, g[2], fmaf(cb.z, r2, cz.z)) : 0.f;
+                    g[3] = r3 > 0.f ? fmaf(ca.w, g[3], fmaf(cb.w, r3, cz.w)) : 0.f;
+                    pk[o].x = cvt_pk_bf16<false>(g[0], g[1]);
+                    pk[o].y = cvt_pk_bf16<false>(g[2], g[3]);
+                    g[0] = __uint_as_float(pk[o].x << 16); g[1] = __uint_as_float(pk[o].x & 0xffff0000u);
+                    g[2] = __uint_as_float(pk[o].y << 16); g[3] = __uint_as_float(pk[o].y & 0xffff0000u);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float w = live ? g[e] : 0.f;
+                    if (st == 0) t1[o * 4 + e] = w; else t1[o * 4 + e] += w;
+                    if constexpr (PASS == 0) {
+                        if (st == 0) t2[o * 4 + e] = w * rv[e]; else t2[o * 4 + e] = fmaf(w, rv[e], t2[o * 4 + e]);
+                    }
+                }
+            }
+            if constexpr (PASS == 1) {
+                const auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+                const u32x4_t c = {sx[0], sy[0], sx[1], sy[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(c, c_rsrc, c_lane, s_out + (uint32_t)(st * 16 * a.ldc + fp * 32) * 2, 0);
+            }
+            if (st == ST - 1) {
+                qs1[fp] += row16_fold8(t1, lane);
+                if constexpr (PASS == 0) qs2[fp] += row16_fold8(t2, lane);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < ST; ++st) dzf[st] = dzn[st];
+    }
+    if (s16 < 8) {
+        const int64_t prow = (int64_t)wkr * 8 + xcd;
+#pragma unroll
+        for (int fp = 0; fp < 2; ++fp) {
+            const int f = f0 + fp * 32 + (s16 >> 2) * 16 + 4 * q4 + (s16 & 3);
+            if constexpr (PASS == 0) {
+                a.partials[(prow * 2 + 0) * a.F + f] = qs1[fp];
+                a.partials[(prow * 2 + 1) * a.F + f] = qs2[fp];
+            } else {
+                a.partials[prow * a.F + f] = qs1[fp];
+            }
+        }
+    }
+}
+
+// grid: 4 workgroups per CU (32 KiB of LDS and ~100 registers each); *stat_rows = partial rows written
+template <int PASS>
+static inline hipError_t launch_proj_dgrad(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
+    if ((a.F & 255) || a.K < 16 || (a.K & 3) || !a.R || (PASS == 1 && !a.coef)) return hipErrorInvalidValue;
+    const int blocks = 1024, nwk = (blocks >> 3) / (a.F >> 8);
+    const int64_t tiles = (a.M + PROJ_RT - 1) / PROJ_RT, workers = (int64_t)nwk * 8;
+    if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
+    hipLaunchKernelGGL(proj_dgrad_kernel<PASS>, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 static inline hipError_t launch_gemm_wsd_bn(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
     if (a.K != WS_K || (a.F & 255) || a.F > 768 || a.lda != WS_K || !a.R) return hipErrorInvalidValue;
     if (!a.coef) {

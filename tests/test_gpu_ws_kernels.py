@@ -1,5 +1,6 @@
 """The weight-stationary data-gradient kernels (csrc/gemm_ws.cuh: with BatchNorm backward in the epilogue, and behind a dropout
-with the mask and the BatchNorm-backward sums) against the tile-staged kernels they replace (CPNATIVE_NO_WSD, read per launch),
+with the mask and the BatchNorm-backward sums; the projection's twice-computed rank-16 gradient) against the tile-staged kernels
+and the separate BatchNorm-backward pass they replace (CPNATIVE_NO_WSD, CPNATIVE_NO_PROJ_FUSED, read per launch),
 element by element on every intermediate gradient of one backward pass behind the SAME forward pass.  Both compute the same sums in a different order, so each tensor agrees to about
 one bf16 ulp of its largest element -- a register-level fault (wrong lanes of a tile, as seen in round 2 whenever a build of
 these kernels went wrong) shows up as isolated elements that are off by the size of the values themselves."""
@@ -22,8 +23,10 @@ def test_ws_kernels_match_tile_staged_kernels_elementwise(dp, monkeypatch):
     for staged in (False, True):
         if staged:
             monkeypatch.setenv("CPNATIVE_NO_WSD", "1")
+            monkeypatch.setenv("CPNATIVE_NO_PROJ_FUSED", "1")
         else:
             monkeypatch.delenv("CPNATIVE_NO_WSD", raising=False)
+            monkeypatch.delenv("CPNATIVE_NO_PROJ_FUSED", raising=False)
         e = Engine(adabn=False, dtype="bf16", dp_emg=dp, device="cuda", seed=123)
         e.init_parameters(5)
         e.grads.flat.zero_()
