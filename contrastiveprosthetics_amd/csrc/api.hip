@@ -451,14 +451,19 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const int Lp = 8;
         const T* A = act(Lp);
         const float *s = stats(Lp) + 2 * 512, *t = stats(Lp) + 3 * 512;
-        if (drop) {
+        // dropout(BN(fc7)) is NOT written out for the projection: its two consumers (this launch and the projection's weight
+        // gradient) form it from the saved activation while staging their operand -- both are bound by reading those 172 MB, and
+        // the pass that materialised it moved 344 MB.  ($CPNATIVE_MATERIALIZE_U8: the separate pass, as fc4..fc6 still have.)
+        const bool fused_u8 = drop && !getenv("CPNATIVE_MATERIALIZE_U8");
+        if (drop && !fused_u8) {
             T* u = (T*)(base + w.u[Lp - 5]);
             ProfScope ps(CP_K_DROPOUT, st);
             hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N, 256 / (512 / D::EPC), 4096)), dim3(256), 0, st,
                                act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c));
             CKL("bn_dropout_apply_kernel");
-            A = u; s = nullptr; t = nullptr;
+            A = u;
         }
+        if (drop) { s = nullptr; t = nullptr; }
         {
             ProfScope ps(CP_K_FOLD, st);
             hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(32), dim3(256), 0, st, p->last_w, (const float*)nullptr, s, t,
@@ -471,7 +476,13 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         a.C = z; a.ldc = CP_D_E; a.f_valid = CP_D_E; a.bias = (float*)(base + w.blast);
         {
             ProfScope ps(CP_K_PROJ_FWD, st);
-            CK((launch_gemm_nt<T, 128, 32, ALOAD_PLAIN, EPI_PLAIN_F32>(a, st)));
+            if (fused_u8) {
+                a.a_scale = stats(Lp) + 2 * 512; a.a_shift = stats(Lp) + 3 * 512;
+                a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c);
+                CK((launch_gemm_nt<T, 128, 32, ALOAD_BNDROP, EPI_PLAIN_F32>(a, st)));
+            } else {
+                CK((launch_gemm_nt<T, 128, 32, ALOAD_PLAIN, EPI_PLAIN_F32>(a, st)));
+            }
         }
     }
     return 0;
@@ -952,7 +963,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         ta.X = dz; ta.ldx = 64; ta.Y = Y; ta.ldy = 512; ta.slabs = slabs; ta.M = N; ta.P = 64; ta.Q = 512;
         int S;
         split_rows(N, 128, &S, &ta.rows_per_split);
-        CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
+        if (drop && !getenv("CPNATIVE_MATERIALIZE_U8")) {
+            // u8 = dropout(BN(fc7)) was never written (encoder_forward_t): formed from the saved activation while staging
+            ta.Y = act(8); ta.y_scale = stats(8) + 2 * 512; ta.y_shift = stats(8) + 3 * 512;
+            ta.dp_thresh = dp_thresh(c->dp_emg); ta.dp_key = dp_key(c, 8); ta.dp_inv_keep = dp_inv_keep(c->dp_emg); ta.dp_salt = dp_salt(c);
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_BNDROP>(ta, S, st)));
+        } else {
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
+        }
         float* praw = (float*)(base + w.praw);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
                            drop ? (float*)nullptr : praw);
@@ -1325,6 +1343,20 @@ extern "C" int cp_debug_activation(const cp_config* cfg, const cp_params* p, con
         return 0;
     }
     const size_t off = layer < CP_N_BN ? w.act[layer] : w.u[layer - CP_N_BN];
+    if (layer == CP_N_BN + 3 && !getenv("CPNATIVE_MATERIALIZE_U8")) {
+        // dropout(BN(fc7)) is not stored by the forward pass (its consumers form it while staging): write it now, same key
+        const int64_t N = cfg->n_windows;
+        const float* st8 = (const float*)(base + w.stats[8]);
+        if (cfg->dtype == CP_BF16)
+            hipLaunchKernelGGL((bn_dropout_apply_kernel<bf16_t>), dim3(grid_rows(N, 256 / (512 / 8), 4096)), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)(base + w.act[8]), st8, (bf16_t*)(base + off), N, 512, dp_thresh(cfg->dp_emg), dp_key(cfg, 8),
+                               dp_inv_keep(cfg->dp_emg), dp_salt(cfg));
+        else
+            hipLaunchKernelGGL((bn_dropout_apply_kernel<float>), dim3(grid_rows(N, 256 / (512 / 4), 4096)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)(base + w.act[8]), st8, (float*)(base + off), N, 512, dp_thresh(cfg->dp_emg), dp_key(cfg, 8),
+                               dp_inv_keep(cfg->dp_emg), dp_salt(cfg));
+        CKL("bn_dropout_apply_kernel(debug)");
+    }
     if (cfg->dtype == CP_BF16)
         hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(1024), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)(base + off), out, n);
     else

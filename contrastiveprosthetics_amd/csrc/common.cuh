@@ -114,6 +114,26 @@ __device__ __forceinline__ float dropout_scale(uint32_t pair, int odd, uint32_t 
     return d >= thresh ? inv_keep : 0.0f;
 }
 
+// one 16-byte chunk of u = dropout(BatchNorm(r)) from the saved activation r, exactly as bn_dropout_apply_kernel writes it
+// (column f.. of row `row` of a [.][C] tensor): consumers that can afford the arithmetic read r and never need u in memory
+template <typename T>
+__device__ __forceinline__ uint4 bn_drop_chunk(const uint4& in, const float* __restrict__ scale, const float* __restrict__ shift, int f,
+                                               uint32_t key, uint32_t row, uint32_t C, uint32_t thresh, float inv_keep) {
+    using D = DT<T>;
+    float v[D::EPC];
+    D::unpack(in, v);
+#pragma unroll
+    for (int e = 0; e < D::EPC; e += 2) {
+        const uint32_t pr = dropout_pair(key, row, C, (uint32_t)(f + e));
+        const f32x2_t keep = {dropout_scale(pr, 0, thresh, inv_keep), dropout_scale(pr, 1, thresh, inv_keep)};
+        const f32x2_t y = __builtin_elementwise_fma((f32x2_t){v[e], v[e + 1]}, (f32x2_t){scale[f + e], scale[f + e + 1]},
+                                                    (f32x2_t){shift[f + e], shift[f + e + 1]}) * keep;
+        v[e] = y.x;
+        v[e + 1] = y.y;
+    }
+    return D::pack(v);
+}
+
 // ---- reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

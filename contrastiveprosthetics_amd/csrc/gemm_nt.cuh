@@ -13,7 +13,8 @@
 #pragma once
 #include "common.cuh"
 
-enum { ALOAD_PLAIN = 0, ALOAD_CONV = 1 };
+enum { ALOAD_PLAIN = 0, ALOAD_CONV = 1,
+       ALOAD_BNDROP = 2 };   // A = dropout(BatchNorm(saved activation)) formed while staging (a_scale/a_shift + the dp_* fields; K = row width)
 enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_PLAIN_F32 = 2,
        EPI_DGRAD_BN = 3,   // persistent kernel: data gradient + BN/ReLU backward of the layer below (GemmNTArgs::coef) against R
        EPI_DGRAD_ST = 4 }; // persistent kernel: data gradient (+ dropout mask) + BN-backward sums against R
@@ -87,9 +88,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int64_t m = m0 + sr + 32 * i;
-            if constexpr (ALOAD == ALOAD_PLAIN) {
+            if constexpr (ALOAD == ALOAD_PLAIN || ALOAD == ALOAD_BNDROP) {
                 const int64_t mc = m < a.M ? m : a.M - 1;
                 uint4 v = *(const uint4*)(Ag + mc * a.lda + k0 + sc * EPC);
+                if constexpr (ALOAD == ALOAD_BNDROP)
+                    v = bn_drop_chunk<T>(v, a.a_scale, a.a_shift, k0 + sc * EPC, a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key, (uint32_t)mc,
+                                         (uint32_t)a.K, a.dp_thresh, a.dp_inv_keep);
                 if (m >= a.M) v = make_uint4(0, 0, 0, 0);
                 areg[i] = v;
             } else {

@@ -9,7 +9,8 @@
 #pragma once
 #include "common.cuh"
 
-enum { YLOAD_PLAIN = 0, YLOAD_CONV = 1 };
+enum { YLOAD_PLAIN = 0, YLOAD_CONV = 1,
+       YLOAD_BNDROP = 2 };   // Y = dropout(BatchNorm(saved activation)) formed while staging (y_scale/y_shift + the dp_* fields; Q = row width)
 
 struct GemmTNArgs {
     const void* X;          // [M][ldx] T
@@ -20,6 +21,10 @@ struct GemmTNArgs {
     int64_t M;
     int64_t rows_per_split; // multiple of 32
     int ldx, ldy, P, Q;
+    // YLOAD_BNDROP: the dropout of the forward pass (as GemmNTArgs)
+    uint32_t dp_thresh, dp_key;
+    const uint32_t* dp_salt;
+    float dp_inv_keep;
 };
 
 template <typename T, int COLS> struct TNPitch {
@@ -97,6 +102,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if constexpr (YLOAD == YLOAD_PLAIN) {
                 if (row < 32 && m < me) v = *(const uint4*)(Yg + m * a.ldy + q0 + ch * EPC);
+            } else if constexpr (YLOAD == YLOAD_BNDROP) {
+                if (row < 32 && m < me)
+                    v = bn_drop_chunk<T>(*(const uint4*)(Yg + m * a.ldy + q0 + ch * EPC), a.y_scale, a.y_shift, q0 + ch * EPC,
+                                         a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key, (uint32_t)m, (uint32_t)a.Q, a.dp_thresh, a.dp_inv_keep);
             } else {
                 // q tile index selects the tap; Y row = activation row m + tap - 1 inside the window
                 const int tap = tq;
