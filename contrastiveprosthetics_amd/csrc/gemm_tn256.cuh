@@ -17,6 +17,7 @@
 #include "common.cuh"
 #include "gemm_tn.cuh"
 #include "gemm_nt256.cuh"      // glds16
+#include "gemm_ws.cuh"         // f32x4_t
 
 #define TN256_STAGES 4
 
@@ -46,6 +47,20 @@ __device__ __forceinline__ uint4 tn256_frag(const unsigned char* tile, int m_off
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
+// the same for v_mfma_f32_16x16x32_bf16: lane (i = lane & 15, kg = lane >> 4) holds rows m_off + 8*kg .. +7 of column col0 + i
+__device__ __forceinline__ uint4 tn256_frag16(const unsigned char* tile, int m_off, int col0, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int row = m_off + 8 * g + q;
+    const int cb = (col0 + 4 * pp) * 2;
+    const unsigned char* p = tile + row * 512 + ((((cb >> 6) ^ (row & 3)) << 6) | (cb & 63));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 512));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+// M16: v_mfma_f32_16x16x32_bf16 (one 32-row step = one k block) instead of 32x32x16 -- measured, not faster (see the launcher)
+template <bool M16>
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
     constexpr int OP_BYTES = 32 * 512;                 // one operand stage: 32 rows x 256 cols bf16
     constexpr int STAGE = 2 * OP_BYTES;
@@ -92,20 +107,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
         }
     };
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) acc[i][jj][g] = 0.f;
-
-    // prologue: up to STAGES-1 steps in flight
-#pragma unroll
-    for (int s = 0; s < TN256_STAGES - 1; ++s)
-        if (s < nsteps) stage(s, s);
-
-    for (int step = 0; step < nsteps; ++step) {
+    float* slab = (second ? a.slabs2 : a.slabs) + (int64_t)split * a.P * a.Q;
+    auto wait_and_stage = [&](int step) {
         // each wave has issued 4 LDS-DMA instructions per step; steps step+1, step+2 may stay in flight
         const int ahead = (nsteps - 1 - step) < (TN256_STAGES - 2) ? (nsteps - 1 - step) : (TN256_STAGES - 2);
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -113,22 +116,33 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                // stage `step` landed for every wave; slot (step-1)%S is free
         if (step + TN256_STAGES - 1 < nsteps) stage((step + TN256_STAGES - 1) % TN256_STAGES, step + TN256_STAGES - 1);
-        const unsigned char* Xs = smem + (step % TN256_STAGES) * STAGE;
-        const unsigned char* Ys = Xs + OP_BYTES;
-        // rows >= me of the last step were loaded from a clamped (valid) row: mask them out of the sum
-        const int valid = (int)(me - (mb + (int64_t)step * 32));      // >= 32 except possibly in the last step
+    };
+    // prologue: up to STAGES-1 steps in flight
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 fx[4], fy[2];
+    for (int s = 0; s < TN256_STAGES - 1; ++s)
+        if (s < nsteps) stage(s, s);
+
+    if constexpr (M16) {
+        f32x4_t acc[8][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fx[i] = tn256_frag(Xs, ks * 16, wp * 128 + i * 32, lane);
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) fy[jj] = tn256_frag(Ys, ks * 16, wq * 64 + jj * 32, lane);
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int step = 0; step < nsteps; ++step) {
+            wait_and_stage(step);
+            const unsigned char* Xs = smem + (step % TN256_STAGES) * STAGE;
+            const unsigned char* Ys = Xs + OP_BYTES;
+            const int valid = (int)(me - (mb + (int64_t)step * 32));      // >= 32 except possibly in the last step
+            uint4 fx[8], fy[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fx[i] = tn256_frag16(Xs, 0, wp * 128 + i * 16, lane);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fy[jj] = tn256_frag16(Ys, 0, wq * 64 + jj * 16, lane);
             if (valid < 32) {
-                // fragment element e of lane half h is row ks*16 + 8h + e: zero the X side of dead rows
-                const int base = ks * 16 + 8 * (lane >> 5);
+                // fragment element e of lane group kg is row 8*kg + e: zero the X side of dead rows
+                const int base = 8 * (lane >> 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 8; ++i) {
                     uint32_t* w = (uint32_t*)&fx[i];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -140,32 +154,90 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
             }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) mma_chunk<bf16_t>(fx[i], fy[jj], acc[i][jj]);
+                for (int jj = 0; jj < 4; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, fx[i]), __builtin_bit_cast(s16x8, fy[jj]), acc[i][jj], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
-    }
-
-    float* slab = (second ? a.slabs2 : a.slabs) + (int64_t)split * a.P * a.Q;
-    const int r = lane & 31, h = lane >> 5;
+        const int cj = lane & 15, rg = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int q = q0 + wq * 64 + jj * 32 + r;
+            for (int jj = 0; jj < 4; ++jj) {
+                const int q = q0 + wq * 64 + jj * 16 + cj;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int p = p0 + wp * 128 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                slab[(int64_t)p * a.Q + q] = acc[i][jj][g];
+                for (int e = 0; e < 4; ++e) {
+                    const int p = p0 + wp * 128 + i * 16 + 4 * rg + e;
+                    slab[(int64_t)p * a.Q + q] = acc[i][jj][e];
+                }
+            }
+    } else {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[i][jj][g] = 0.f;
+        for (int step = 0; step < nsteps; ++step) {
+            wait_and_stage(step);
+            const unsigned char* Xs = smem + (step % TN256_STAGES) * STAGE;
+            const unsigned char* Ys = Xs + OP_BYTES;
+            // rows >= me of the last step were loaded from a clamped (valid) row: mask them out of the sum
+            const int valid = (int)(me - (mb + (int64_t)step * 32));      // >= 32 except possibly in the last step
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 fx[4], fy[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fx[i] = tn256_frag(Xs, ks * 16, wp * 128 + i * 32, lane);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) fy[jj] = tn256_frag(Ys, ks * 16, wq * 64 + jj * 32, lane);
+                if (valid < 32) {
+                    // fragment element e of lane half h is row ks*16 + 8h + e: zero the X side of dead rows
+                    const int base = ks * 16 + 8 * (lane >> 5);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t* w = (uint32_t*)&fx[i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t lo = (base + 2 * e) < valid ? 0xFFFFu : 0u;
+                            const uint32_t hi = (base + 2 * e + 1) < valid ? 0xFFFF0000u : 0u;
+                            w[e] &= (lo | hi);
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) mma_chunk<bf16_t>(fx[i], fy[jj], acc[i][jj]);
+                __builtin_amdgcn_s_setprio(0);
             }
         }
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int q = q0 + wq * 64 + jj * 32 + r;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int p = p0 + wp * 128 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    slab[(int64_t)p * a.Q + q] = acc[i][jj][g];
+                }
+            }
+    }
 }
 
 static inline hipError_t launch_gemm_tn256(const GemmTN256Args& a, hipStream_t st) {
     const int ntiles = (a.P / 256) * (a.Q / 256);
     const int groups = (a.splits + 7) / 8;
     const int problems = a.X2 ? 2 : 1;
-    hipLaunchKernelGGL(gemm_tn256_kernel, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a);
+    // ($CPNATIVE_TN16: the 16x16x32 form.  Measured in the step, alternating runs on one box: 137.0 / 150.6 us per launch against
+    //  134.5 / 147.2 for the 32x32x16 form -- the shape that gained 18 % in the weight-stationary forward gains nothing here, where
+    //  both operands come through ds_read_b64_tr_b16 at 0.75 fragment reads per MFMA-equivalent either way.)
+    if (getenv("CPNATIVE_TN16")) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a);
     return hipGetLastError();
 }
