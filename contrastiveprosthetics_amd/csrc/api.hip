@@ -514,7 +514,9 @@ extern "C" int cp_global_negatives(const cp_params* p, const float* z_all, int64
     hipStream_t st = (hipStream_t)stream;
     float* pos = scratch;
     float* part = scratch + n_all_windows;
-    const int blocks = grid_rows(n_all_windows, 256, kHeadBlocksMax);
+    // one workgroup per CU: each wave ends with 41 cross-lane sums, so several windows per thread beat more workgroups
+    // (tools/gneg_bench.py, 1 / 8 ranks' rows: 37 / 123 us with 256 workgroups, 59 / 153 with up to 1024)
+    const int blocks = grid_rows(n_all_windows, 256, 256);
     ProfScope ps(CP_K_HEAD, st);
     hipLaunchKernelGGL(gneg_g_kernel, dim3(blocks), dim3(256), 0, st, z_all, n_all_windows, p->easy_w, p->easy_b, labels, part, pos);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(GNEG_PART)), dim3(FIN_THREADS), 0, st, part, blocks, GNEG_PART, gh_out);
