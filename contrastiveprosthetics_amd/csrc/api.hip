@@ -386,6 +386,15 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         ProfScope ps(CP_K_PREP, st);
         hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
         CKL("prep_conv2_kernel");
+        if (drop) {
+            // the weights of the layers behind a dropout (fc5..fc7, projection) carry no BatchNorm fold: plain copies, all in one launch
+            FoldBatch fb{};
+            for (int q = 0; q < 3; ++q)
+                fb.job[q] = FoldJob{p->fc_w[4 + q], p->fc_b[4 + q], base + w.wfc[4 + q], (float*)(base + w.bfc[4 + q]), 512, 512, 512};
+            fb.job[3] = FoldJob{p->last_w, nullptr, base + w.wlast, (float*)(base + w.blast), CP_D_E, 512, 32};
+            hipLaunchKernelGGL((fold_copy_batch_kernel<T>), dim3(512, 4), dim3(256), 0, st, fb);
+            CKL("fold_copy_batch_kernel");
+        }
     }
     // conv1
     {
@@ -426,7 +435,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
         }
-        {
+        if (!(drop && Lp >= 5)) {          // (the layers behind a dropout were copied by fold_copy_batch_kernel above)
             ProfScope ps(CP_K_FOLD, st);
             hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(512), dim3(256), 0, st, p->fc_w[i], p->fc_b[i], s, t,
                                (T*)(base + w.wfc[i]), (float*)(base + w.bfc[i]), 512, K, i == 0 ? 1 : 0);
@@ -463,8 +472,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
             CKL("bn_dropout_apply_kernel");
             A = u;
         }
-        if (drop) { s = nullptr; t = nullptr; }
-        {
+        if (!drop) {                       // (with dropout: copied by fold_copy_batch_kernel at the start of the pass)
             ProfScope ps(CP_K_FOLD, st);
             hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(32), dim3(256), 0, st, p->last_w, (const float*)nullptr, s, t,
                                (T*)(base + w.wlast), (float*)(base + w.blast), CP_D_E, 512, 0);

@@ -149,6 +149,21 @@ __global__ __launch_bounds__(256) void fold_linear_kernel(const float* __restric
     if (tid == 0 && out_b != nullptr && j < F) out_b[j] = (b ? b[j] : 0.f) + red[0] + red[1] + red[2] + red[3];
 }
 
+// plain copies (no BatchNorm fold: the layers behind a dropout, whose input already is dropout(BN(.))) of several layers in ONE
+// launch at the start of the forward pass (blockIdx.y = job, blockIdx.x = output row; rows >= rows_out of a job: nothing to do) --
+// they do not wait for any statistics, so they need not sit between the GEMMs as four ~5 us launches
+struct FoldJob { const float* W; const float* b; void* out_w; float* out_b; int F, K, rows_out; };
+struct FoldBatch { FoldJob job[4]; };
+template <typename T>
+__global__ __launch_bounds__(256) void fold_copy_batch_kernel(FoldBatch fb) {
+    using D = DT<T>;
+    const FoldJob& jb = fb.job[blockIdx.y];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (j >= jb.rows_out) return;
+    for (int k = tid; k < jb.K; k += 256) D::store((T*)jb.out_w + (int64_t)j * jb.K + k, j < jb.F ? jb.W[(int64_t)j * jb.K + k] : 0.f);
+    if (tid == 0 && jb.out_b != nullptr && j < jb.F) jb.out_b[j] = jb.b ? jb.b[j] : 0.f;
+}
+
 // transposed copy for the data-gradient GEMM:  out[k'][j] = W[j][k]   (ld_out >= F, zero padded)
 template <typename T>
 __global__ void transpose_w_kernel(const float* __restrict__ W, T* __restrict__ out, int F, int K, int ld_out, int mode) {
