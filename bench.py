@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--cpu_seconds", type=float, default=15.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel-kind times to stderr")
-    ap.add_argument("--profile_every", type=int, default=10,
+    ap.add_argument("--profile_every", type=int, default=20,
                     help="bracket the fc GEMM launches with HIP events (the live roofline numbers) on every n-th timed step")
     ap.add_argument("--global_negatives", default="auto", choices=["auto", "on", "off"],
                     help="auto: on when N > 1 (BASELINE config[2] names the z all-gather; it must have a reader), off at N = 1")
