@@ -435,10 +435,29 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
                     acc.t[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ft][kb], __builtin_bit_cast(s16x8, fa[st]), acc.t[ft][st], 0, 0, 0);
                 if (kb + 1 < KB) fa[st] = *(const uint4*)(At + st * 16384 + ((((kb + 1) * 4) << 4) ^ d16));
             }
+#ifdef WS16_WOVEN_EPI
             if constexpr (WITH_EPI)
                 if (kb >= 6 && kb < 6 + 2 * ST) epi_slot(old, kb - 6, s_old, all_live);
+#endif
         }
+#ifndef WS16_WOVEN_EPI
+        // The previous tile's epilogue runs BEHIND the k loop, not inside it: with the matrix pipe of every CU busy, vector
+        // instructions issued beside the MFMAs cost more than their own time (tools/coissue_probe.hip: 257 us of MFMAs + 141 us of
+        // FMAs take 472 us interleaved); measured in the step 99-101 us per launch against 106-107 woven (-DWS16_WOVEN_EPI).
+        if constexpr (WITH_EPI) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2 * ST; ++u) epi_slot(old, u, s_old, all_live);
+            __builtin_amdgcn_sched_barrier(0);
+            // the row fetches are older than the 2*ST stores just issued: wait for them only (vmcnt retires in order)
+            static_assert(2 * ST == 6, "the wait below counts the epilogue's stores");
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
     };
     auto drain = [&](Ws16Acc& old, int64_t m_old) {
@@ -831,9 +850,21 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_kernel(GemmNTArgs a) {
                     acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ft][kb], __builtin_bit_cast(s16x8, fa[st]), acc[ft][st], 0, 0, 0);
                 if (kb + 1 < KB) fa[st] = *(const uint4*)(At + st * 16384 + ((((kb + 1) * 4) << 4) ^ d16));
             }
+            // (woven into the k loop here: behind the loop, as gemm_ws16_kernel has it, the BN mode measured the same and the
+            //  dropout mode 10 us slower -- -DWSD16_SERIAL_EPI)
+#ifndef WSD16_SERIAL_EPI
             if constexpr (WITH_EPI)
                 if (kb >= 4 && kb < 4 + 2 * 2 * ST && (kb & 1) == 0) epi_slot(old, Rw, (kb - 4) >> 1, s_old, all_live, m_old);
+#endif
         }
+#ifdef WSD16_SERIAL_EPI
+        if constexpr (WITH_EPI) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2 * ST; ++u) epi_slot(old, Rw, u, s_old, all_live, m_old);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
