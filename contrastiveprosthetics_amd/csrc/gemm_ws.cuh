@@ -444,6 +444,8 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
         // The previous tile's epilogue runs BEHIND the k loop, not inside it: with the matrix pipe of every CU busy, vector
         // instructions issued beside the MFMAs cost more than their own time (tools/coissue_probe.hip: 257 us of MFMAs + 141 us of
         // FMAs take 472 us interleaved); measured in the step 99-101 us per launch against 106-107 woven (-DWS16_WOVEN_EPI).
+        // It stays the PREVIOUS tile's epilogue (two accumulator sets): with one set and the tile's own epilogue behind its k loop
+        // the epilogue waits for the last MFMAs and the next tile's first MFMAs for the epilogue -- 114-119 us.
         if constexpr (WITH_EPI) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
