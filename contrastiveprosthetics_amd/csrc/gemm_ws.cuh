@@ -852,22 +852,21 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_kernel(GemmNTArgs a) {
                     acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ft][kb], __builtin_bit_cast(s16x8, fa[st]), acc[ft][st], 0, 0, 0);
                 if (kb + 1 < KB) fa[st] = *(const uint4*)(At + st * 16384 + ((((kb + 1) * 4) << 4) ^ d16));
             }
-            // (woven into the k loop here: behind the loop, as gemm_ws16_kernel has it, the BN mode measured the same and the
-            //  dropout mode 10 us slower -- -DWSD16_SERIAL_EPI)
-#ifndef WSD16_SERIAL_EPI
-            if constexpr (WITH_EPI)
+            // MODE 1 (dropout): woven into the k loop; MODE 0 (BN): behind it, as in gemm_ws16_kernel.  Measured in the step,
+            // alternating runs: BN mode 131 us behind the loop against 136 woven, dropout mode 135 against 126.
+            if constexpr (WITH_EPI && STATS)
                 if (kb >= 4 && kb < 4 + 2 * 2 * ST && (kb & 1) == 0) epi_slot(old, Rw, (kb - 4) >> 1, s_old, all_live, m_old);
-#endif
         }
-#ifdef WSD16_SERIAL_EPI
-        if constexpr (WITH_EPI) {
+        if constexpr (WITH_EPI && !STATS) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 2 * ST; ++u) epi_slot(old, Rw, u, s_old, all_live, m_old);
             __builtin_amdgcn_sched_barrier(0);
+            static_assert(2 * ST == 4, "the wait below counts the epilogue's stores");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                 // the fetches are older than the 4 stores
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
     auto drain = [&](f32x4_t (&old)[4][ST], int buf, int64_t m_old) {
