@@ -451,7 +451,10 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int u = 0; u < 2 * ST; ++u) epi_slot(old, u, s_old, all_live);
             __builtin_amdgcn_sched_barrier(0);
-            // the row fetches are older than the 2*ST stores just issued: wait for them only (vmcnt retires in order)
+            // the row fetches are older than the 2*ST stores just issued: wait for them only.  (vmcnt retires an LDS-DMA load
+            // before every younger store: tools/vmcnt_order_probe.hip, 5e8 lane-reads behind vmcnt(1/4/6) without a stale one,
+            // 99.8 % stale with the count one too high.  Safe alternatives measured slower: wait + barrier in front of the
+            // epilogue 100-102 us, the outputs held in registers until the barrier is passed 100-102 us, this 94-97 us.)
             static_assert(2 * ST == 6, "the wait below counts the epilogue's stores");
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
