@@ -42,7 +42,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 # ({dyn} = the tile schedule, include/cpnative.h cp_set_tile_schedule: "false" static, "true" dynamic)
 GEMM_KERNELS = {
     "fc_fwd_ws": "gemm_ws16_kernel",                      # weight-stationary forward, fc2..fc7 (K = 512), static schedule
-    "fc_fwd": "gemm_nt256p_kernel<0, 4, {dyn}>",          # persistent, bias + ReLU + BN sums in the epilogue: fc1 (K = 768)
+    "fc_fwd": "gemm_ws16k_kernel",                        # weight-stationary with the k range split over wave pairs: fc1 (K = 768)
     "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
     "fc_dgrad_bn": "gemm_wsd16_kernel<0>",                # weight-stationary, + BN/ReLU backward of the layer below against the saved activation
     "fc_dgrad_stats": "gemm_wsd16_kernel<1>",             # weight-stationary, behind a dropout: mask + BN-backward sums against the saved activation
@@ -56,6 +56,8 @@ def gemm_symbol(kind: str, dyn: str) -> str:
     env = os.environ
     if kind == "fc_fwd_ws" and env.get("CPNATIVE_WS32"):
         return "gemm_ws_kernel<0, 4>"
+    if kind == "fc_fwd" and (env.get("CPNATIVE_NO_WS") or env.get("CPNATIVE_NO_WSK")):
+        return "gemm_nt256p_kernel<0, 4, %s>" % dyn
     if kind == "fc_dgrad_bn":
         if env.get("CPNATIVE_NO_WSD"):
             return "gemm_nt256p_kernel<3, 4, %s>" % dyn

@@ -296,6 +296,10 @@ static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int
         // (dbg 256, tools only: the tile-staged kernel instead; $CPNATIVE_NO_WS does the same for a whole process)
         if (EPI == EPI_FWD && a.K == WS_K && a.lda == WS_K && a.relu && !dyn && !(a.dbg & (16 | 256)) && !getenv("CPNATIVE_NO_WS"))
             return launch_gemm_ws<EPI_FWD>(a, st, stat_rows);
+        // fc1 (K = 768), same conditions: the split-k weight-stationary kernel ($CPNATIVE_NO_WSK: the tile-staged kernel)
+        if (EPI == EPI_FWD && a.K == WSK_K && a.lda == WSK_K && a.F == 512 && a.relu && !dyn && !(a.dbg & (16 | 256)) && !getenv("CPNATIVE_NO_WS") &&
+            !getenv("CPNATIVE_NO_WSK"))
+            return launch_gemm_ws16k(a, st, stat_rows);
         if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows, dyn);
         // BatchNorm + ReLU backward in the data-gradient epilogue, static schedule: the weight-stationary form (gemm_ws.cuh)
         // (and, behind a dropout, the mask + BatchNorm-backward sums; $CPNATIVE_NO_WSD_ST keeps that one on the tile-staged kernel)
