@@ -662,7 +662,9 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16k_kernel(GemmNTArgs a) {
         for (int st = 0; st < ST; ++st) fa[st] = *(const uint4*)(At + st * 16 * WSK_ROWB + (0 ^ d16));
 #pragma unroll
         for (int kb = 0; kb < KBH; ++kb) {
+#ifndef WSK_NO_FETCH
             fetch_unit(next_soff, buf ^ 1, kb);
+#endif
 #pragma unroll
             for (int st = 0; st < ST; ++st) {
 #pragma unroll
@@ -1206,7 +1208,10 @@ __global__ __launch_bounds__(256, 2) void proj_dgrad_kernel(GemmNTArgs a) {
     for (int ti = 0; ti < ntile; ++ti) {
         const int buf = ti & 1;
         const int64_t m0 = row0(ti);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this tile's R sub-tile has landed (own DMA only)
+        // this tile's R sub-tile has landed (own DMA only).  PASS 1: the previous tile's 2*ST stores are younger than that fetch and
+        // stay in flight (tools/vmcnt_order_probe.hip)
+        if (PASS == 1 && ti > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (ti + 1 < ntile) { fetch_r(row0(ti + 1), buf ^ 1); load_dz(row0(ti + 1), dzn); }
         f32x4_t acc[4][ST];
 #pragma unroll
