@@ -926,8 +926,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_kernel(GemmNTArgs a) {
     constexpr int RT = WSD16_RT, TILE_BYTES = RT * WS_K * 2, R_BYTES = RT * 128;          // R: per wave and buffer, rows of 64 features
     constexpr int K = WS_K, KB = K / 32, RPW = RT / 4, ST = RT / 16;
     constexpr int R_OFF = 2 * TILE_BYTES, COEF_OFF = R_OFF + 4 * 2 * R_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[COEF_OFF + 3 * 256 * 4];
-    float* coef_s = (float*)(smem + COEF_OFF);                               // [3][256]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[COEF_OFF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -940,13 +939,24 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_kernel(GemmNTArgs a) {
     const int first = wkr * 8 + xcd, stride = nwk * 8;
     const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
     if (ntile == 0) return;
-    if constexpr (!STATS)
-        for (int q = tid; q < 3 * 256; q += 256) {
-            const int c = q >> 8, f = fb * 256 + (q & 255);
-            coef_s[q] = a.coef[c * a.coef_mod + f % a.coef_mod];
-        }
     const uint32_t dkey = (STATS && a.dp_thresh != 0) ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
-    const int f0 = fb * 256 + wave * 64, fl0 = wave * 64;
+    const int f0 = fb * 256 + wave * 64;
+    // MODE 0: the three BatchNorm-backward coefficients of this lane's 16 features stay in registers (48 of them; read from an LDS
+    // table per epilogue slot they were 6 of its 8 ds_read_b128)
+    float4 cfa[STATS ? 1 : 4], cfb[STATS ? 1 : 4], cfz[STATS ? 1 : 4];
+    if constexpr (!STATS) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            float v[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[c][e] = a.coef[c * a.coef_mod + (f0 + ft * 16 + 4 * (lane >> 4) + e) % a.coef_mod];
+            cfa[ft] = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+            cfb[ft] = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+            cfz[ft] = make_float4(v[2][0], v[2][1], v[2][2], v[2][3]);
+        }
+    }
 
     s16x8 wreg[4][KB];
     {
@@ -1001,8 +1011,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd16_kernel(GemmNTArgs a) {
             const float r2 = __uint_as_float(rr.y << 16), r3 = __uint_as_float(rr.y & 0xffff0000u);
             float y0 = old[ft][st][0], y1 = old[ft][st][1], y2 = old[ft][st][2], y3 = old[ft][st][3];
             if constexpr (!STATS) {
-                const int fl = fl0 + ft * 16 + 4 * q4;
-                const float4 ca = *(const float4*)(coef_s + fl), cb = *(const float4*)(coef_s + 256 + fl), cz = *(const float4*)(coef_s + 512 + fl);
+                const float4 ca = cfa[ft], cb = cfb[ft], cz = cfz[ft];
                 y0 = r0 > 0.f ? fmaf(ca.x, y0, fmaf(cb.x, r0, cz.x)) : 0.f;
                 y1 = r1 > 0.f ? fmaf(ca.y, y1, fmaf(cb.y, r1, cz.y)) : 0.f;
                 y2 = r2 > 0.f ? fmaf(ca.z, y2, fmaf(cb.z, r2, cz.z)) : 0.f;
