@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -175,3 +176,13 @@ def test_register_stationary_gemm_kernel_has_no_spills():
     assert len(lines) >= 6, out
     for l in lines:
         assert re.search(r"spill\s+0\s+scratch\s+0\b", l), l
+
+
+def test_no_buffer_store_is_followed_by_a_write_of_its_data_registers():
+    """gfx950 store-data hazard (csrc/gemm_ws.cuh, store_b128_settled; DESIGN.md section 4, "The lanes 12-15 fault"): hipcc places a
+    VALU write of a buffer_store_dwordx4's data registers directly behind the store when the store's soffset is an SGPR, and the
+    store then sends the new values for some lanes.  tools/store_hazard_scan.py reads the device assembly of the whole library: no
+    96/128-bit buffer store may have such a write within the next two instructions."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "store_hazard_scan.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.strip().startswith("0 unprotected"), out.stdout[-500:]
