@@ -537,6 +537,8 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
 // LDS-DMA units of 1 KiB run across row boundaries, the 16-byte chunks are XOR-swizzled with the row inside 256-byte groups (applied to
 // the DMA's per-lane source), so the 16 rows of a fragment read fall on 16 different chunk positions.  Partial rows: two per worker
 // (one per k half: a wave only sums the tiles it owned).
+// Measured against it: all 384 weight registers in ONE wave (256 in the accumulator file + 128 vector registers, MFMA takes its A operand
+// from either; no exchange, 192 MFMAs per tile as in the K = 512 kernel) -- parity-green, but 24 spilled registers and 261 us.
 #define WSK_K 768
 #define WSK_RT 32
 #define WSK_ROWB (WSK_K * 2)
@@ -657,21 +659,25 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16k_kernel(GemmNTArgs a) {
             acc[ft][1] = pick(k0, zv, bv);
         }
         const unsigned char* At = smem + buf * WSK_TILE_BYTES + s16 * WSK_ROWB + kh * (KH * 2);
-        uint4 fa[ST];
+        // fragments of k block kb + 1 are requested in front of the 8 MFMAs of block kb (two register sets): with only two sample tiles
+        // a re-read right behind its consumer (gemm_ws16_kernel) would have 4 MFMAs = 64 cycles to return
+        uint4 fa[2][ST];
 #pragma unroll
-        for (int st = 0; st < ST; ++st) fa[st] = *(const uint4*)(At + st * 16 * WSK_ROWB + (0 ^ d16));
+        for (int st = 0; st < ST; ++st) fa[0][st] = *(const uint4*)(At + st * 16 * WSK_ROWB + (0 ^ d16));
 #pragma unroll
         for (int kb = 0; kb < KBH; ++kb) {
 #ifndef WSK_NO_FETCH
             fetch_unit(next_soff, buf ^ 1, kb);
 #endif
+            if (kb + 1 < KBH) {
 #pragma unroll
-            for (int st = 0; st < ST; ++st) {
+                for (int st = 0; st < ST; ++st) fa[(kb + 1) & 1][st] = *(const uint4*)(At + st * 16 * WSK_ROWB + ((((kb + 1) * 4) << 4) ^ d16));
+            }
+#pragma unroll
+            for (int st = 0; st < ST; ++st)
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft)
-                    acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ft][kb], __builtin_bit_cast(s16x8, fa[st]), acc[ft][st], 0, 0, 0);
-                if (kb + 1 < KBH) fa[st] = *(const uint4*)(At + st * 16 * WSK_ROWB + ((((kb + 1) * 4) << 4) ^ d16));
-            }
+                    acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ft][kb], __builtin_bit_cast(s16x8, fa[kb & 1][st]), acc[ft][st], 0, 0, 0);
         }
         // this wave's sums of the partner's rows go to the partner: slot [feature group][buffer][receiving k half]
         unsigned char* Xo = smem + X_OFF + ((fg * 2 + buf) * 2 + (kh ^ 1)) * (X_BYTES / 2);
