@@ -315,6 +315,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmNTAr
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // 48-row tiles (3 sample tiles of 16): with 64 rows the two accumulator sets (128 registers) + 256 weight registers + fragments
 // left hipcc 24 registers short (6 weight fragments spilled and reloaded every tile -- and spills are fatal here, see above)
+// (64-row tiles fit without spills once the epilogue sits behind the k loop -- 214 registers -- and measured 97-98 us against 96)
 #define WS16_RT 48
 #define WS16_ST (WS16_RT / 16)
 #define WS16_TILE_BYTES (WS16_RT * WS_K * 2)
