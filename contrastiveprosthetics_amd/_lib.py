@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CPNATIVE_LIB: another build of the same library (A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("CPNATIVE_LIB") or os.path.join(_HERE, "libcpnative.so")
 
-CP_F32, CP_BF16 = 0, 1
+CP_F32, CP_BF16, CP_FP8 = 0, 1, 2
+FP8_STATE_BYTES = 1024            # scale table at the start of a CP_FP8 workspace (csrc/fp8.cuh): zero once after allocating
 CP_TASKS, CP_EMG_DIM, CP_D_E, CP_N_BN, CP_N_FC = 41, 12, 16, 9, 7
 
 _fp = C.c_void_p

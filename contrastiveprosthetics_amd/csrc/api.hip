@@ -21,6 +21,7 @@
 #include "eval.cuh"
 #include "preprocess.cuh"
 #include "glove.cuh"
+#include "fp8.cuh"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* what) {
@@ -163,6 +164,9 @@ struct WS {
     size_t praw;             // f32 [512][768]: raw (un-fixed) weight-gradient product of the current layer
     size_t head_part;        // f32
     size_t sync_loc, sync_glob;   // f32 [2][768] each: one row of statistics, this rank's and the sum over ranks (sync BN)
+    // CP_FP8 (csrc/fp8.cuh): the scale table (ALWAYS at offset 0, so that it survives a change of n_windows), the e4m3 activations,
+    // dropout outputs and fc weights with their scale bytes; the 16-bit buffers above are then what the bf16 backward kernels read
+    size_t f8state, act8[CP_N_BN], u8[3], wfc8[CP_N_FC], wsc8[CP_N_FC];
     size_t total;
     size_t partials_floats, slabs_floats;
 };
@@ -171,10 +175,19 @@ static const int kHeadBlocksMax = 1024;
 static const int kSumSlices = 16;           // row slices (= partial rows) of bn_bwd_sums_from_wgrad_kernel
 
 static WS carve(int64_t N, int dtype, float dp) {
-    WS w;
-    const size_t es = dtype == CP_BF16 ? 2 : 4;
+    WS w{};
+    const size_t es = dtype == CP_F32 ? 4 : 2;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    if (dtype == CP_FP8) {
+        w.f8state = take(F8_STATE_BYTES);
+        for (int l = 1; l < CP_N_BN; ++l) w.act8[l] = take((size_t)N * (l < 2 ? 768 : 512));
+        for (int i = 0; i < 3; ++i) w.u8[i] = dp > 0.f ? take((size_t)N * 512) : 0;
+        for (int i = 0; i < CP_N_FC; ++i) {
+            w.wfc8[i] = take((size_t)512 * fcK(i));
+            w.wsc8[i] = take(512);
+        }
+    }
     // (conv1's output is never stored: act[0] is empty, its consumers recompute it from x)
     for (int l = 0; l < CP_N_BN; ++l) w.act[l] = take(l == 0 ? 0 : (size_t)N * (l < 2 ? 768 : 512) * es);
     for (int i = 0; i < 4; ++i) w.u[i] = dp > 0.f ? take((size_t)N * 512 * es) : 0;
@@ -237,7 +250,7 @@ static float dp_inv_keep(float p) { return 1.0f / (1.0f - (float)dp_thresh(p) / 
 static int check_cfg(const cp_config* c, void* ws, size_t ws_bytes, WS* out) {
     if (!c || !ws) return fail(CP_ERR_ARG, "null config/workspace");
     if (c->n_windows <= 0 || c->n_windows % CP_TASKS != 0) return fail(CP_ERR_ARG, "n_windows must be a positive multiple of 41");
-    if (c->dtype != CP_F32 && c->dtype != CP_BF16) return fail(CP_ERR_ARG, "dtype");
+    if (c->dtype != CP_F32 && c->dtype != CP_BF16 && c->dtype != CP_FP8) return fail(CP_ERR_ARG, "dtype");
     if (c->dp_emg < 0.f || c->dp_emg >= 1.f) return fail(CP_ERR_ARG, "dp_emg");
     *out = carve(c->n_windows, c->dtype, c->dp_emg);
     if (out->total > ws_bytes) return fail(CP_ERR_WORKSPACE, "workspace too small");
@@ -500,12 +513,139 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// encoder forward, CP_FP8 (csrc/fp8.cuh): conv stack on the bf16 kernels with conv2's output stored as e4m3, fc1..fc7 on the
+// block-scaled MFMA with e4m3 activations and weights, projection on the bf16 kernel with its operand converted while staging
+// ---------------------------------------------------------------------------------------
+static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_bn_buffers* bn, const float* x,
+                               unsigned char* base, const WS& w, float* z, hipStream_t st) {
+    using T = bf16_t;
+    using D = DT<T>;
+    const int64_t N = c->n_windows, R12 = N * 12;
+    const bool batch_stats = c->training || c->adabn;
+    const bool have_running = bn && bn->running_mean[0] && bn->running_var[0];
+    if (!batch_stats && !have_running) return fail(CP_ERR_ARG, "eval with stock BN needs running statistics");
+    if (g_sync_fn) return fail(CP_ERR_ARG, "CP_FP8: synchronised BatchNorm is not wired into the 8-bit path");
+    if (tile_schedule() == CP_TILES_DYNAMIC) return fail(CP_ERR_ARG, "CP_FP8 runs the static tile schedule only");
+    if ((uint64_t)N * 768 >= 0xFFF00000ull) return fail(CP_ERR_ARG, "CP_FP8: n_windows * 768 must stay below 2^32 (32-bit buffer offsets)");
+    const int upd = (c->training && !c->adabn && have_running) ? 1 : 0;
+    const bool drop = c->training && c->dp_emg > 0.f;
+    float* partials = (float*)(base + w.partials);
+    Fp8State* fs = (Fp8State*)(base + w.f8state);
+    auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
+    auto finalize = [&](int l, int nrows, double count, const int* unscale) -> int {
+        ProfScope ps(CP_K_BN_FINALIZE, st);
+        const int C = kLayerC[l];
+        const PreReduce pre{partials, (float*)(base + w.partials2), st};
+        const float* pp = batch_stats ? pre(nrows, 2 * C) : partials;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
+                           have_running ? bn->running_mean[l] : nullptr, have_running ? bn->running_var[l] : nullptr, upd,
+                           batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats(l), C, unscale);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail((int)e, "bn_finalize_kernel");
+    };
+    {
+        ProfScope ps(CP_K_PREP, st);
+        hipLaunchKernelGGL(fp8_update_scales_kernel, dim3(1), dim3(64), 0, st, fs, N);
+        hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
+        CKL("prep kernels (fp8)");
+    }
+    // conv1 (statistics only) and conv2 (output as e4m3)
+    {
+        constexpr int RPP = 256 / (64 / D::EPC);
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int g = (int)((need + passes - 1) / passes);
+        {
+            ProfScope ps(CP_K_CONV1_FWD, st);
+            hipLaunchKernelGGL((conv1_stats_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, partials, R12);
+            CKL("conv1_stats_kernel");
+        }
+        if (int e = finalize(0, g, (double)R12, nullptr)) return e;
+    }
+    {
+        ConvArgs ca{};
+        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0);
+        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = nullptr; ca.partials = partials; ca.n_windows = N;
+        ca.out8 = base + w.act8[1]; ca.out_exp = &fs->e[F8_T_ACT + 1]; ca.out_amax = &fs->amax[F8_T_ACT + 1];
+        const int g = conv_grid<T>(N);
+        {
+            ProfScope ps(CP_K_CONV2_FWD, st);
+            hipLaunchKernelGGL((conv2_strip_kernel<T, 0>), dim3(g), dim3(256), 0, st, ca);
+            CKL("conv2_strip_kernel<fwd, e4m3>");
+        }
+        if (int e = finalize(1, g, (double)R12, nullptr)) return e;      // (its sums are of the bf16-rounded values in true units)
+    }
+    // fc1..fc7
+    for (int i = 0; i < CP_N_FC; ++i) {
+        const int L = 2 + i, Lp = L - 1, K = fcK(i);
+        const bool in_drop = drop && Lp >= 5;
+        const uint8_t* A = base + w.act8[Lp];
+        int t_in = F8_T_ACT + Lp;
+        const float *s = stats(Lp) + 2 * kLayerC[Lp], *t = stats(Lp) + 3 * kLayerC[Lp];
+        if (in_drop) {
+            uint8_t* u = base + w.u8[Lp - 5];
+            t_in = F8_T_U + (Lp - 5);
+            ProfScope ps(CP_K_DROPOUT, st);
+            hipLaunchKernelGGL(bn_dropout_apply8_kernel, dim3(grid_rows(N, 256 / (512 / 16), 4096)), dim3(256), 0, st, A, stats(Lp), u, N, 512,
+                               dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c), fs, F8_T_ACT + Lp, t_in);
+            CKL("bn_dropout_apply8_kernel");
+            A = u; s = nullptr; t = nullptr;
+        }
+        {
+            ProfScope ps(CP_K_FOLD, st);
+            hipLaunchKernelGGL(fold_linear8_kernel, dim3(512), dim3(256), 0, st, p->fc_w[i], p->fc_b[i], s, t, base + w.wfc8[i], base + w.wsc8[i],
+                               (float*)(base + w.bfc[i]), K, i == 0 ? 1 : 0, fs, t_in, F8_T_ACT + L);
+            CKL("fold_linear8_kernel");
+        }
+        Ws8Args a{};
+        a.A = A; a.W = base + w.wfc8[i]; a.wsc = base + w.wsc8[i]; a.bias = (float*)(base + w.bfc[i]);
+        a.C = base + w.act8[L]; a.partials = partials; a.amax = &fs->amax[F8_T_ACT + L]; a.M = N; a.F = 512;
+        int nrows = 0;
+        {
+            ProfScope ps(K == 512 ? CP_K_FC_FWD_WS : CP_K_FC_FWD, st);
+            if (K == 512) CK(launch_gemm_ws8<512>(a, st, &nrows));
+            else CK(launch_gemm_ws8<768>(a, st, &nrows));
+        }
+        if (int e = finalize(L, nrows, (double)N, &fs->e[F8_T_ACT + L])) return e;
+    }
+    // projection 512 -> 16 on the bf16 kernel: its operand is read as e4m3 and converted (and, with dropout, turned into
+    // dropout(BN(fc7))) while staging
+    {
+        const int Lp = 8;
+        const float *s = stats(Lp) + 2 * 512, *t = stats(Lp) + 3 * 512;
+        {
+            ProfScope ps(CP_K_FOLD, st);
+            if (drop) hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(32), dim3(256), 0, st, p->last_w, (const float*)nullptr, (const float*)nullptr,
+                                         (const float*)nullptr, (T*)(base + w.wlast), (float*)(base + w.blast), CP_D_E, 512, 0);
+            else hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(32), dim3(256), 0, st, p->last_w, (const float*)nullptr, s, t,
+                                    (T*)(base + w.wlast), (float*)(base + w.blast), CP_D_E, 512, 0);
+            CKL("fold_linear_kernel(last)");
+        }
+        GemmNTArgs a{};
+        a.A = base + w.act8[Lp]; a.lda = 512; a.M = N; a.K = 512;
+        a.W = base + w.wlast; a.F = 32;
+        a.C = z; a.ldc = CP_D_E; a.f_valid = CP_D_E; a.bias = (float*)(base + w.blast);
+        a.a_exp = &fs->e[F8_T_ACT + Lp];
+        ProfScope ps(CP_K_PROJ_FWD, st);
+        if (drop) {
+            a.a_scale = s; a.a_shift = t;
+            a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c);
+            CK((launch_gemm_nt<T, 128, 32, ALOAD_BNDROP_F8, EPI_PLAIN_F32>(a, st)));
+        } else {
+            CK((launch_gemm_nt<T, 128, 32, ALOAD_F8, EPI_PLAIN_F32>(a, st)));
+        }
+    }
+    return 0;
+}
+
 extern "C" int cp_encoder_forward(const cp_config* cfg, const cp_params* p, const cp_bn_buffers* bn, const float* x,
                                   void* ws, size_t ws_bytes, float* z_out, void* stream) {
     WS w;
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !z_out) return fail(CP_ERR_ARG, "cp_encoder_forward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
+    if (cfg->dtype == CP_FP8) return encoder_forward_fp8(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
     if (cfg->dtype == CP_BF16)
         return encoder_forward_t<bf16_t>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
     return encoder_forward_t<float>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
@@ -566,7 +706,7 @@ static int head_impl(const cp_config* cfg, const cp_params* p, const float* z, c
     if (want_grad && (!grads || !grads->easy_w || !grads->easy_b)) return fail(CP_ERR_ARG, "cp_head grads");
     hipStream_t st = (hipStream_t)stream;
     unsigned char* base = (unsigned char*)ws;
-    const size_t es = cfg->dtype == CP_BF16 ? 2 : 4;
+    const size_t es = cfg->dtype == CP_F32 ? 4 : 2;
     ProfScope ps(CP_K_HEAD, st);
     if (want_grad) CK(hipMemsetAsync(base + w.dz, 0, (size_t)cfg->n_windows * 64 * es, st));
     HeadArgs a{};
@@ -575,7 +715,7 @@ static int head_impl(const cp_config* cfg, const cp_params* p, const float* z, c
     a.logits = logits; a.pred = pred; a.partials = (float*)(base + w.head_part);
     a.gneg = gneg;
     const int blocks = grid_rows(n_groups, HEAD_WAVES, kHeadBlocksMax);
-    if (cfg->dtype == CP_BF16)
+    if (cfg->dtype != CP_F32)
         hipLaunchKernelGGL((head_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((head_kernel<float>), dim3(blocks), dim3(256), 0, st, a);
@@ -1230,6 +1370,24 @@ extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, 
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !grads) return fail(CP_ERR_ARG, "cp_encoder_backward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
+    if (cfg->dtype == CP_FP8) {
+        // (bridge, while the 8-bit backward kernels are being built: the e4m3 tensors of the forward pass are expanded to bf16 --
+        //  exactly -- and the bf16 backward kernels run on them)
+        unsigned char* base = (unsigned char*)ws;
+        hipStream_t st = (hipStream_t)stream;
+        const Fp8State* fs = (const Fp8State*)(base + w.f8state);
+        const int64_t N = cfg->n_windows;
+        const bool drop = cfg->training && cfg->dp_emg > 0.f;
+        for (int l = 1; l < CP_N_BN; ++l) {
+            const int64_t n16 = N * (l < 2 ? 768 : 512) / 16;
+            hipLaunchKernelGGL(dequant8_bf16_kernel, dim3(grid_rows(n16, 256, 4096)), dim3(256), 0, st, base + w.act8[l], (bf16_t*)(base + w.act[l]), n16, fs, F8_T_ACT + l);
+        }
+        if (drop)
+            for (int i = 0; i < 3; ++i)
+                hipLaunchKernelGGL(dequant8_bf16_kernel, dim3(grid_rows(N * 32, 256, 4096)), dim3(256), 0, st, base + w.u8[i], (bf16_t*)(base + w.u[i]), N * 32, fs, F8_T_U + i);
+        CKL("dequant8_bf16_kernel");
+        return encoder_backward_t<bf16_t>(cfg, p, x, base, w, grads, st, (hipEvent_t)fc_grads_ready);
+    }
     if (cfg->dtype == CP_BF16)
         return encoder_backward_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
     return encoder_backward_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
@@ -1347,13 +1505,22 @@ extern "C" int cp_debug_activation(const cp_config* cfg, const cp_params* p, con
     if (layer == 0) {   // conv1's output is never stored: recompute it exactly as its consumers do
         if (!p || !x) return fail(CP_ERR_ARG, "layer 0 needs params and x");
         const int64_t rows = cfg->n_windows * 12;
-        if (cfg->dtype == CP_BF16)
+        if (cfg->dtype != CP_F32)
             hipLaunchKernelGGL((conv1_materialize_kernel<bf16_t>), dim3(1024), dim3(256), 0, (hipStream_t)stream, x, p->conv1_w,
                                p->conv1_b, out, rows);
         else
             hipLaunchKernelGGL((conv1_materialize_kernel<float>), dim3(1024), dim3(256), 0, (hipStream_t)stream, x, p->conv1_w,
                                p->conv1_b, out, rows);
         CKL("conv1_materialize_kernel");
+        return 0;
+    }
+    if (cfg->dtype == CP_FP8) {
+        // the stored e4m3 tensor in true units (dropout(BN(fc7)), layer CP_N_BN + 3, is never stored on this path)
+        if (layer == CP_N_BN + 3) return fail(CP_ERR_ARG, "CP_FP8: dropout(BN(fc7)) is formed while staging and never stored");
+        const int t = layer < CP_N_BN ? F8_T_ACT + layer : F8_T_U + (layer - CP_N_BN);
+        const uint8_t* src = base + (layer < CP_N_BN ? w.act8[layer] : w.u8[layer - CP_N_BN]);
+        hipLaunchKernelGGL(dequant8_f32_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, src, out, n, (const Fp8State*)(base + w.f8state), t);
+        CKL("dequant8_f32_kernel");
         return 0;
     }
     const size_t off = layer < CP_N_BN ? w.act[layer] : w.u[layer - CP_N_BN];

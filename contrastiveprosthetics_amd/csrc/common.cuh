@@ -70,6 +70,21 @@ template <> struct DT<bf16_t> {
     __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+// ---- OCP e4m3 storage (CP_FP8; csrc/fp8.cuh): tensors carry one power-of-two scale, kept as an exponent in device memory ----
+__device__ __forceinline__ float f8_exp2i(int e) { return __int_as_float((127 + e) << 23); }      // 2^e, |e| < 127
+// 4 e4m3 bytes -> f32 x4 (stored units)
+__device__ __forceinline__ void f8_unpack4(uint32_t w, float* o) {
+    const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
+}
+// 8 e4m3 bytes times d -> one 16-byte chunk of bf16
+__device__ __forceinline__ uint4 f8_chunk_to_bf16(const uint2& raw, float d) {
+    float v[8];
+    f8_unpack4(raw.x, v);
+    f8_unpack4(raw.y, v + 4);
+    return make_uint4(pack2bf(v[0] * d, v[1] * d), pack2bf(v[2] * d, v[3] * d), pack2bf(v[4] * d, v[5] * d), pack2bf(v[6] * d, v[7] * d));
+}
+
 // ---- MFMA on one 16-byte chunk pair ---------------------------------------------
 // a: chunk of the MFMA "A" operand row (lane&31), k-range selected by lane>>5
 // b: chunk of the MFMA "B" operand column (lane&31), same k-range.

@@ -26,6 +26,9 @@ struct ConvArgs {
     const float* bias2;     // conv_emg.3.bias (forward)
     const void* gin;        // [N*12][64] T gradient wrt conv2's pre-BN output (dgrad / wgrad)
     void* out;              // forward: r2, dgrad: g_v1   [N*12][64] T
+    uint8_t* out8;          // forward, CP_FP8: r2 as e4m3 [N*12][64] INSTEAD of `out`, scale 2^*out_exp, running maximum in *out_amax
+    const int* out_exp;
+    uint32_t* out_amax;
     float* partials;        // [grid][2][64] (fwd: sum, sumsq of r2; dgrad: sum g, sum g*r1) / wgrad: slabs [grid][64][192]
     int64_t n_windows;
 };
@@ -192,6 +195,9 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
     // three at a time, in front of every image row's arithmetic: 153 -> 137 us).  MODE 1 recomputes r1 in its store-out
     // loop, where the same change cost 38 us (128 -> 166): it keeps reading x from global memory.
     __shared__ float xs[MODE == 0 ? 2 : 1][MODE == 0 ? CONV_WPB * 12 : 1];
+    // CP_FP8 forward: scale of the e4m3 output and the largest scaled value this thread stored
+    float out_scale = 1.f, out_max = 0.f;
+    if constexpr (MODE == 0 && sizeof(T) == 2) { if (a.out8 != nullptr) out_scale = f8_exp2i(*a.out_exp); }
     unsigned char* img = smem;
     unsigned char* Cs = smem;                      // aliases the image once the MFMAs are done
     unsigned char* Wl = smem + REGION;
@@ -359,10 +365,29 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
                     s2[k] = __builtin_elementwise_fma(vp, rp, s2[k]);
                 }
             }
+            if constexpr (MODE == 0 && sizeof(T) == 2) {
+                if (a.out8 != nullptr) {
+                    // CP_FP8: the eight values of the chunk as e4m3 with the tensor's scale (v >= 0: clamp from above only)
+                    float w8[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { w8[e] = v[e] * out_scale; out_max = fmaxf(out_max, w8[e]); w8[e] = fminf(w8[e], 448.f); }
+                    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[0], w8[1], 0, false), p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[4], w8[5], 0, false);
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[2], w8[3], p0, true);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], p1, true);
+                    if (ok) *(uint2*)(a.out8 + m * 64 + cc * EPC) = make_uint2((uint32_t)p0, (uint32_t)p1);
+                    continue;
+                }
+            }
             if (ok) *(uint4*)((T*)a.out + m * 64 + cc * EPC) = c;
         }
         __syncthreads();                           // output tile dead before the next image is staged
         xb ^= 1;
+    }
+    if constexpr (MODE == 0 && sizeof(T) == 2) {
+        if (a.out8 != nullptr) {
+            out_max = wave_max(out_max);
+            if ((tid & 63) == 0 && out_max > 0.f) atomicMax(a.out_amax, __float_as_uint(out_max));
+        }
     }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { red[(0 * RPP + rr) * 64 + cc * EPC + e] = s1[e / 2][e & 1]; red[(1 * RPP + rr) * 64 + cc * EPC + e] = s2[e / 2][e & 1]; }

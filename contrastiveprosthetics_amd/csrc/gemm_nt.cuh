@@ -14,7 +14,9 @@
 #include "common.cuh"
 
 enum { ALOAD_PLAIN = 0, ALOAD_CONV = 1,
-       ALOAD_BNDROP = 2 };   // A = dropout(BatchNorm(saved activation)) formed while staging (a_scale/a_shift + the dp_* fields; K = row width)
+       ALOAD_BNDROP = 2,     // A = dropout(BatchNorm(saved activation)) formed while staging (a_scale/a_shift + the dp_* fields; K = row width)
+       ALOAD_F8 = 3,         // A is stored as e4m3 (one byte per element, lda in bytes) with the scale 2^*a_exp: converted to T while staging
+       ALOAD_BNDROP_F8 = 4 };// both
 enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_PLAIN_F32 = 2,
        EPI_DGRAD_BN = 3,   // persistent kernel: data gradient + BN/ReLU backward of the layer below (GemmNTArgs::coef) against R
        EPI_DGRAD_ST = 4 }; // persistent kernel: data gradient (+ dropout mask) + BN-backward sums against R
@@ -30,6 +32,7 @@ struct GemmNTArgs {
     int coef_mod;        //   the epilogue then writes  r > 0 ? ca*g + cb*r + cz : 0  (feature f uses entry f % coef_mod)
     const float* a_scale;  // ALOAD_CONV affine per input channel (64) or nullptr
     const float* a_shift;
+    const int* a_exp;      // ALOAD_F8 / ALOAD_BNDROP_F8: device word holding the scale exponent of A (stored = value * 2^e)
     int64_t M;
     int lda, ldc, ldr;
     int K, F;
@@ -77,6 +80,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
     constexpr int A_IT = BM / 32, W_IT = BN / 32;
     uint4 areg[A_IT], wreg[W_IT];
     const int sc = tid & 7, sr = tid >> 3;
+    float a_deq = 1.f;
+    if constexpr (ALOAD == ALOAD_F8 || ALOAD == ALOAD_BNDROP_F8) a_deq = f8_exp2i(-*a.a_exp);
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
@@ -88,10 +93,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int64_t m = m0 + sr + 32 * i;
-            if constexpr (ALOAD == ALOAD_PLAIN || ALOAD == ALOAD_BNDROP) {
+            if constexpr (ALOAD == ALOAD_PLAIN || ALOAD == ALOAD_BNDROP || ALOAD == ALOAD_F8 || ALOAD == ALOAD_BNDROP_F8) {
                 const int64_t mc = m < a.M ? m : a.M - 1;
-                uint4 v = *(const uint4*)(Ag + mc * a.lda + k0 + sc * EPC);
-                if constexpr (ALOAD == ALOAD_BNDROP)
+                uint4 v;
+                if constexpr (ALOAD == ALOAD_F8 || ALOAD == ALOAD_BNDROP_F8) {
+                    static_assert(sizeof(T) == 2 || (ALOAD != ALOAD_F8 && ALOAD != ALOAD_BNDROP_F8), "e4m3 operands feed the bf16 kernels");
+                    v = f8_chunk_to_bf16(*(const uint2*)((const uint8_t*)a.A + mc * a.lda + k0 + sc * 8), a_deq);
+                } else {
+                    v = *(const uint4*)(Ag + mc * a.lda + k0 + sc * EPC);
+                }
+                if constexpr (ALOAD == ALOAD_BNDROP || ALOAD == ALOAD_BNDROP_F8)
                     v = bn_drop_chunk<T>(v, a.a_scale, a.a_shift, k0 + sc * EPC, a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key, (uint32_t)mc,
                                          (uint32_t)a.K, a.dp_thresh, a.dp_inv_keep);
                 if (m >= a.M) v = make_uint4(0, 0, 0, 0);

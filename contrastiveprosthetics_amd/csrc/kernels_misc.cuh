@@ -80,7 +80,7 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* _
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, int update_running,
                                                           int use_running, float momentum, float eps,
-                                                          float* __restrict__ stats, int C) {
+                                                          float* __restrict__ stats, int C, const int* __restrict__ unscale_exp = nullptr) {
     __shared__ double red[2][FIN_THREADS / 64][FIN_COLS];
     const int tid = threadIdx.x, cl = tid % FIN_COLS, g = tid / FIN_COLS;
     const int c = blockIdx.x * FIN_COLS + cl;
@@ -91,6 +91,11 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* _
     }
     s1 = fin_block_sum(s1, red[0], tid);
     s2 = fin_block_sum(s2, red[1], tid);
+    if (unscale_exp != nullptr) {          // CP_FP8: the sums are of values stored with the scale 2^e (exact to undo)
+        const double d = (double)f8_exp2i(-*unscale_exp);
+        s1 *= d;
+        s2 *= d * d;
+    }
     if (g == 0 && c < C) {
         float mean, var;
         if (use_running) {

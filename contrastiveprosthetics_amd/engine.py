@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CP_BF16, CP_D_E, CP_F32, CP_N_BN, CP_N_FC, CP_TASKS
+from ._lib import CP_BF16, CP_D_E, CP_F32, CP_FP8, CP_N_BN, CP_N_FC, CP_TASKS
 
 LINEAR_IDX = (0, 3, 6, 9, 13, 17, 21)           # code/models.py:266-298
 LINEAR_BN_IDX = (2, 5, 8, 11, 15, 19, 23)
@@ -176,14 +176,16 @@ class Engine:
         self.class_encoder = class_encoder
         if d_e != CP_D_E:
             raise ValueError(f"the HIP head kernel is built for d_e={CP_D_E} (code/train.py:183), got {d_e}")
-        if dtype not in ("f32", "bf16"):
-            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if dtype not in ("f32", "bf16", "fp8"):
+            raise ValueError("dtype must be 'f32', 'bf16' or 'fp8'")
+        if dtype == "fp8" and class_encoder != "onehot":
+            raise ValueError("dtype 'fp8' (BASELINE config 4) covers the one-hot class encoder")
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.CpNativeError("contrastiveprosthetics_amd runs on an MI355X (device 'cuda') only; no CPU path")
         self.adabn = bool(adabn)
-        self.dtype = CP_BF16 if dtype == "bf16" else CP_F32
+        self.dtype = {"f32": CP_F32, "bf16": CP_BF16, "fp8": CP_FP8}[dtype]
         self.dp_emg = float(dp_emg)
         self.seed = int(seed)
         self.step_count = 0              # forward passes in train mode (dropout stream)
@@ -264,6 +266,9 @@ class Engine:
             nbytes = self.lib.cp_workspace_bytes(n_windows, self.dtype, self.dp_emg)
             self._ws = None                                   # (frees the old block first unless a GraphStep holds it)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            if self.dtype == CP_FP8:
+                # the tensors' scales live here across steps (csrc/fp8.cuh, Fp8State): a fresh workspace starts from the defaults
+                self._ws[:_lib.FP8_STATE_BYTES].zero_()
             self._ws_windows = n_windows
         return self._ws
 
@@ -497,6 +502,13 @@ class Engine:
         _lib.check(self.lib.cp_debug_bn_stats(C.byref(cfg), ws, nb, layer, out.data_ptr(), self._stream()),
                    "cp_debug_bn_stats")
         return out
+
+    def fp8_scale_exponents(self) -> torch.Tensor:
+        """CP_FP8: the scale table of the current workspace (csrc/fp8.cuh, Fp8State.e): stored = value * 2^e[t]; t = layer l for the
+        saved activation of layer l (1..8), 9 + i for the dropout output feeding fc5 + i.  One host sync."""
+        if self.dtype != CP_FP8 or self._ws is None:
+            raise _lib.CpNativeError("no CP_FP8 workspace")
+        return self._ws[:256].view(torch.int32).cpu()
 
     # ------------------------------------------------------------------ profiling (bench.py)
     def profile_enable(self, kinds=None, max_records: int = 4096):

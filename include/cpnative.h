@@ -31,6 +31,7 @@ extern "C" {
 #define CP_VERSION 100            /* 0.1.0 */
 #define CP_F32 0
 #define CP_BF16 1
+#define CP_FP8 2                  /* e4m3 activations and fc weights on the block-scaled MFMA (BASELINE config 4); see cp_config.dtype */
 #define CP_TASKS 41               /* code/constants.py:45-48 */
 #define CP_EMG_DIM 12             /* code/constants.py:97 */
 #define CP_D_E 16                 /* embedding width (code/train.py:183) */
@@ -64,7 +65,8 @@ typedef struct cp_bn_buffers {
 
 typedef struct cp_config {
     int64_t n_windows;   /* rows through the encoder = groups * 41 (train: B*41, eval: B*41*25) */
-    int32_t dtype;       /* CP_F32 | CP_BF16 */
+    int32_t dtype;       /* CP_F32 | CP_BF16 | CP_FP8 (the first F8_STATE_BYTES = 1024 bytes of a CP_FP8 workspace hold the tensors' scales across
+                          * steps: zero them once after allocating it) */
     int32_t adabn;       /* 1: batch statistics in train AND eval (AdaBN); 0: stock BN */
     int32_t training;    /* 1: model.train()  (batch stats, dropout, running-stat update) */
     uint32_t step_state_lo; /* low / high half of the DEVICE address of a cp_step_state, or 0/0 (see below) */

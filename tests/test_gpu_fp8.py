@@ -1,0 +1,162 @@
+"""The 8-bit path (BASELINE config 4, dtype="fp8": e4m3 activations and fc weights on the block-scaled MFMA), on a real MI355X.
+
+Parity is UNPINNED by construction: the reference only gestures at reduced precision (code/train.py:6,37,56,97 -- `amp` imported,
+`autocast` commented out), so there is nothing of its own to compare 8-bit numbers with.  What is checked instead:
+  * every fc kernel against an emulation of ITS OWN arithmetic in torch (same quantised weights, same stored input bytes, f32
+    accumulation): outputs equal up to one e4m3 step on a small fraction of elements -- this is the test that sees a wrong lane map;
+  * the path as a whole against the f32 HIP path and the CPU oracle: distances REPORTED, gated on finiteness and on the loss.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as oc
+
+pytestmark = pytest.mark.gpu
+
+BEST = dict(d_e=16, lr_emg=9.761e-4, reg_emg=7.103e-5, dp_emg=0.0,
+            lr_glove=2.653e-3, reg_glove=2.840e-6, dp_glove=0.0)
+T = oc.N_TASKS
+LINEAR_IDX = (0, 3, 6, 9, 13, 17, 21)
+
+
+def randn(seed, shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def make_engine(sd, adabn, dtype, dp=0.0, seed=0):
+    from contrastiveprosthetics_amd.engine import Engine
+    e = Engine(adabn=adabn, dtype=dtype, dp_emg=dp, device="cuda", seed=seed)
+    e.load_named(sd)
+    return e
+
+
+def nontrivial_sd(seed, adabn):
+    sd = oc.init_state_dict(seed, 16, adabn)
+    g = torch.Generator().manual_seed(seed + 1)
+    for b in oc.bn_bases(adabn):
+        sd[b + ".weight"] = 1.0 + 0.2 * torch.randn(sd[b + ".weight"].shape, generator=g)
+        sd[b + ".bias"] = 0.1 * torch.randn(sd[b + ".bias"].shape, generator=g)
+    return sd
+
+
+def fit_exp(amax, target):
+    """largest e with amax * 2^e <= target (fp8.cuh, f8_fit_exp)"""
+    ma, xa = np.frexp(amax.astype(np.float32))
+    mt, xt = np.frexp(np.float32(target))
+    e = xt - xa - (ma > mt)
+    return np.where(amax > 0, e, 0).astype(np.int64)
+
+
+def e4m3(t):
+    """round to e4m3 as the kernels do: clamp, then nearest-even"""
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+@pytest.mark.parametrize("B", [64, 3])
+def test_fc_kernels_against_their_own_arithmetic(B):
+    adabn = False
+    sd = nontrivial_sd(31, adabn)
+    EMG = randn(501, (B, T, 1, 1, 12))
+    e = make_engine(sd, adabn, "fp8")
+    x = EMG.reshape(-1, 12).cuda()
+    e.encoder_forward(x, training=True)          # first pass: default scales, fills the maxima
+    e.encoder_forward(x, training=True)          # second pass: scales chosen from the first
+    torch.cuda.synchronize()
+    ex = e.fp8_scale_exponents().numpy()
+    n = x.shape[0]
+    worst_frac = 0.0
+    for i, li in enumerate(LINEAR_IDX):
+        L, Lp = 2 + i, 1 + i
+        r_in = e.debug_activation(Lp).double()                     # stored input, true units (exact)
+        r_out = e.debug_activation(L).double()
+        st = e.debug_bn_stats(Lp).double()
+        C = 64 if Lp < 2 else 512
+        s, t = st[2], st[3]
+        W = sd[f"emg_net.linear.{li}.weight"].cuda().double()
+        b = sd[f"emg_net.linear.{li}.bias"].cuda().double()
+        if Lp < 2:                                                 # internal order k' = w*64 + c of the reference's k = c*12 + w
+            W = W.reshape(512, 64, 12).permute(0, 2, 1).reshape(512, 768)
+            s, t = s.repeat(12), t.repeat(12)
+        Wf = W * s[None, :]
+        bf = b + (W * t[None, :]).sum(1)
+        ej = torch.from_numpy(fit_exp(Wf.abs().amax(1).float().cpu().numpy(), 448.0)).cuda()
+        Wq = e4m3((Wf.float() * torch.exp2(ej.float())[:, None])).double()
+        ei, eo = int(ex[Lp]), int(ex[L])
+        xq = r_in * 2.0 ** ei                                      # stored bytes as numbers
+        y = (xq @ Wq.T) * torch.exp2((eo - ei) - ej.double())[None, :] + bf[None, :] * 2.0 ** eo
+        want = e4m3(y.clamp(min=0).float()).double() * 2.0 ** -eo
+        diff = (r_out - want).abs()
+        step = want.abs() * 0.125 + 2.0 ** (-9 - eo)               # one e4m3 step at that magnitude (3 mantissa bits)
+        assert bool((diff <= 1.001 * step).all()), f"fc{i + 1}: an output is more than one e4m3 step from the emulation"
+        frac = float((diff > 0).double().mean())
+        worst_frac = max(worst_frac, frac)
+        assert frac < 0.02, f"fc{i + 1}: {frac:.4f} of the outputs differ from the emulation (rounding ties only expected)"
+        # BatchNorm statistics of the layer: of the clamped, un-rounded outputs
+        yt = y.clamp(0, 448.0) * 2.0 ** -eo
+        st_out = e.debug_bn_stats(L).double()
+        mean, var = yt.mean(0), yt.var(0, unbiased=False)
+        assert float((st_out[0] - mean).abs().max()) < 2e-4 * float(mean.abs().max() + 1e-6), f"fc{i + 1} mean"
+        assert float((st_out[1] - 1.0 / torch.sqrt(var + 1e-5)).abs().max() / st_out[1].abs().max()) < 2e-3, f"fc{i + 1} invstd"
+    print(f"\nfp8 fc kernels vs emulation at {n} rows: at most {worst_frac:.5f} of a layer's outputs differ (by one e4m3 step)")
+
+
+@pytest.mark.parametrize("adabn", [False, True])
+def test_forward_against_f32_and_oracle(adabn):
+    B = 16
+    sd = nontrivial_sd(41, adabn)
+    EMG = randn(502, (B, T, 1, 1, 12))
+    label = torch.arange(T).repeat(B)
+    m = oc.OracleModel(sd, BEST, adabn=adabn)
+    logits_ref = m.forward(EMG, torch.zeros(B, T, 20), label)
+    loss_ref = float(m.loss(logits_ref, label))
+    x = EMG.reshape(-1, 12).cuda()
+    res = {}
+    for dt in ("f32", "bf16", "fp8"):
+        e = make_engine(sd, adabn, dt)
+        for _ in range(2):                       # (fp8: the second pass runs with calibrated scales)
+            z = e.encoder_forward(x, training=True)
+        out, pred, logits = e.head(z, label.cuda(), 1, want_grad=False, want_logits=True)
+        torch.cuda.synchronize()
+        res[dt] = (float(out[0]), pred.cpu().numpy(), logits.cpu().numpy())
+    lf = res["fp8"][2]
+    assert np.isfinite(lf).all()
+    d_or = np.abs(lf - logits_ref.numpy())
+    d_bf = np.abs(res["bf16"][2] - logits_ref.numpy())
+    agree = float((res["fp8"][1] == logits_ref.argmax(-1).numpy()).mean())
+    agree_bf = float((res["bf16"][1] == logits_ref.argmax(-1).numpy()).mean())
+    print(f"\nfp8 vs f32 oracle at B={B} (adabn={adabn}): max |dlogit| {d_or.max():.4f} rms {np.sqrt((d_or ** 2).mean()):.5f} argmax agreement {agree:.4f}"
+          f"   [bf16: max {d_bf.max():.4f} rms {np.sqrt((d_bf ** 2).mean()):.5f} agreement {agree_bf:.4f}]   loss fp8 {res['fp8'][0]:.5f} "
+          f"bf16 {res['bf16'][0]:.5f} oracle {loss_ref:.5f}")
+    assert abs(res["fp8"][0] - loss_ref) < 0.01 * abs(loss_ref), "fp8 loss differs from the oracle's by more than 1 %"
+    assert np.sqrt((d_or ** 2).mean()) < 0.08, "fp8 logits: rms distance to the oracle"
+
+
+def test_step_runs_and_learns():
+    """whole training steps (forward in 8 bits, backward through the bf16 bridge) next to the bf16 path: same data, same seeds"""
+    from contrastiveprosthetics_amd.engine import Engine
+    B, steps = 32, 60
+    sd = oc.init_state_dict(7, 16, False)
+    g = torch.Generator().manual_seed(99)
+    mu = torch.randn(T, 12, generator=g)
+    label = torch.arange(T).repeat(B).cuda()
+    curves = {}
+    for dt in ("bf16", "fp8"):
+        e = Engine(adabn=False, dtype=dt, dp_emg=0.0635, device="cuda", seed=3)
+        e.load_named(sd)
+        gg = torch.Generator().manual_seed(1234)
+        losses = []
+        for s in range(steps):
+            x = (mu[None] + torch.randn(B, T, 12, generator=gg)).reshape(-1, 12).cuda()
+            z = e.encoder_forward(x, training=True)
+            out, pred, _ = e.head(z, label, 1, want_grad=True)
+            e.encoder_backward(x)
+            e.adam_step(BEST)
+            losses.append(float(out[0]))
+        curves[dt] = np.array(losses)
+        assert np.isfinite(curves[dt]).all(), dt
+    a, b = curves["bf16"], curves["fp8"]
+    print(f"\nloss over {steps} steps: bf16 {a[0]:.4f} -> {a[-10:].mean():.4f}, fp8 {b[0]:.4f} -> {b[-10:].mean():.4f}; "
+          f"max |difference| of the 10-step means {np.abs(a.reshape(-1, 10).mean(1) - b.reshape(-1, 10).mean(1)).max():.4f}")
+    assert b[-10:].mean() < b[:5].mean() - 0.3, "the fp8 path does not learn"
+    assert abs(b[-10:].mean() - a[-10:].mean()) < 0.05 * a[-10:].mean(), "fp8 and bf16 loss curves part by more than 5 %"
