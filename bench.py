@@ -35,7 +35,7 @@ T = 41
 BEST = dict(d_e=16, lr_emg=9.761e-4, reg_emg=7.103e-5, dp_emg=0.0635,
             lr_glove=2.653e-3, reg_glove=2.840e-6, dp_glove=0.3817)   # reference data/cross_val_keys.npy[54]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}
 
 
 # profiler kind -> (the ONE kernel it times, as rocprofv3 names it; fc layer indices it runs on when dropout is on / off)
@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch_size", type=int, default=4096, help="groups of 41 windows per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--adabn", action="store_true", help="AdaBN instead of stock BN (--no_adabn is BASELINE config 1)")
     ap.add_argument("--dp_emg", type=float, default=BEST["dp_emg"])
     ap.add_argument("--cpu_seconds", type=float, default=15.0)
@@ -296,7 +296,7 @@ def main():
         print(f"  sum            {tot / 2:8.3f} ms/step", file=sys.stderr)
 
     if rank == 0:
-        es = 2 if args.dtype == "bf16" else 4
+        es = 4 if args.dtype == "f32" else 2
         dom = max(gemm_kinds, key=lambda k: prof.get(k, (0.0, 0))[0])
         ms, launches = prof[dom]
         mfma_busy = None                 # counter evidence, from the committed SQ pass of this same command (tools/profile_round.sh)

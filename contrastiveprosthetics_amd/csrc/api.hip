@@ -167,6 +167,7 @@ struct WS {
     // CP_FP8 (csrc/fp8.cuh): the scale table (ALWAYS at offset 0, so that it survives a change of n_windows), the e4m3 activations,
     // dropout outputs and fc weights with their scale bytes; the 16-bit buffers above are then what the bf16 backward kernels read
     size_t f8state, act8[CP_N_BN], u8[3], wfc8[CP_N_FC], wsc8[CP_N_FC];
+    size_t g8[2], wfc8t[CP_N_FC], wsc8t[CP_N_FC];      // backward: e5m2 gradient ping-pong [N][512], W^T as e4m3 [K][512] + scale bytes [K]
     size_t total;
     size_t partials_floats, slabs_floats;
 };
@@ -186,7 +187,10 @@ static WS carve(int64_t N, int dtype, float dp) {
         for (int i = 0; i < CP_N_FC; ++i) {
             w.wfc8[i] = take((size_t)512 * fcK(i));
             w.wsc8[i] = take(512);
+            w.wfc8t[i] = take((size_t)512 * fcK(i));
+            w.wsc8t[i] = take(768);
         }
+        for (int i = 0; i < 2; ++i) w.g8[i] = take((size_t)N * 512);
     }
     // (conv1's output is never stored: act[0] is empty, its consumers recompute it from x)
     for (int l = 0; l < CP_N_BN; ++l) w.act[l] = take(l == 0 ? 0 : (size_t)N * (l < 2 ? 768 : 512) * es);
@@ -1055,6 +1059,100 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
     *splits = (int)((M + rps - 1) / rps);
 }
 
+// conv stack of the backward pass (shared by the 16/32-bit and the 8-bit fc paths): cur = dL/d(BN2 output), or dL/d(conv2
+// pre-activation) when bn_done, as [N][768] == [(N*12)][64] T; nxt = scratch of the same size
+template <typename T>
+static int conv_backward_tail(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
+                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows) {
+    using D = DT<T>;
+    const int64_t N = c->n_windows, R12 = N * 12;
+    float* partials = (float*)(base + w.partials);
+    float* slabs = (float*)(base + w.slabs);
+    float* coef = (float*)(base + w.coef);
+    auto act = [&](int l) { return (T*)(base + w.act[l]); };
+    auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
+    int conv_dgrad_rows = 0;
+    const PreReduce pre{partials, (float*)(base + w.partials2), st};
+    auto bwd_finalize = [&](const float* pp, int nr, double count, int l, int C, int nfold, const char* what) -> int {
+        const float* local = nullptr;
+        if (g_sync_fn) {
+            if (int e = sync_row(pp, nr, 2 * C * nfold, base, w, st, &pp, &local)) return e;
+            nr = 1;
+            count *= g_sync_world;
+        }
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nr, count, stats(l), coef, g->bn_g[l],
+                           g->bn_b[l], C, nfold, local);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail((int)e, what);
+    };
+    // every gradient but the conv stack's is final here (cp_encoder_backward_ev): a data-parallel caller starts summing
+    // them across ranks while the conv backward below still runs
+    if (fc_grads_ready) CK(hipEventRecord(fc_grads_ready, st));
+    // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
+    {
+        if (!bn_done) {
+            ProfScope ps(CP_K_BN_BWD, st);
+            int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
+            const float* pp = pre(nr, 2 * 768);
+            if (int e = bwd_finalize(pp, nr, (double)R12, 1, 64, 12, "bn_bwd_finalize_kernel(conv2)")) return e;
+            const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
+            hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
+            nr = gb;
+            pp = pre(nr, 64);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
+            CKL("bn_relu_bwd_kernel(conv2)");
+        }
+        if (int e = tap_gradient(1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
+        ConvArgs ca{};
+        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0); ca.gin = cur; ca.n_windows = N;
+        {
+            ProfScope ps(CP_K_CONV2_WGRAD, st);
+            const int64_t strips = (N + CONV_WG_WPB - 1) / CONV_WG_WPB;
+            const int64_t cap = sizeof(T) == 2 ? 512 : 256;      // two blocks per CU (194 registers with the strip prefetch)
+            const int S = (int)(strips < cap ? strips : cap);
+            ca.partials = slabs;
+            hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
+            // up to 512 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
+            // unused tail of the slab buffer), then the scatter kernel walks 32 instead of 512
+            const float* sl = slabs;
+            int ns = S;
+            if (S > 2 * REDUCE_SLICES) {
+                float* folded = slabs + (size_t)S * 64 * 192;
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(64 * 192 / 64, REDUCE_SLICES), dim3(256), 0, st, slabs, S, 64 * 192, folded);
+                sl = folded;
+                ns = REDUCE_SLICES;
+            }
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, sl, ns, 64, 192, 64, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2, (float*)nullptr);
+            CKL("conv2_wgrad_kernel");
+        }
+        conv_dgrad_rows = conv_grid<T>(N);
+        ca.wc = base + w.wc2_d; ca.out = nxt; ca.partials = partials;
+        {
+            ProfScope ps(CP_K_CONV2_DGRAD, st);
+            hipLaunchKernelGGL((conv2_strip_kernel<T, 1>), dim3(conv_dgrad_rows), dim3(256), 0, st, ca);
+            CKL("conv2_strip_kernel<dgrad>");
+        }
+    }
+    if (int e = tap_gradient(0, nxt, N, 768, sizeof(T), st)) return e;             // dL/d(BN1 output), [w][c]
+    // ---- conv1 -----------------------------------------------------------------------------
+    {
+        ProfScope ps(CP_K_CONV1_BWD, st);
+        int nr = conv_dgrad_rows;
+        const float* pp = pre(nr, 2 * 64);
+        if (int e = bwd_finalize(pp, nr, (double)R12, 0, 64, 1, "bn_bwd_finalize_kernel(conv1)")) return e;
+        constexpr int RPP = 256 / (64 / D::EPC);                      // windows per block and pass
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int gb = (int)((need + passes - 1) / passes);           // every block makes the same number of passes
+        hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, x, p->conv1_w, p->conv1_b, coef, partials, R12);
+        nr = gb;
+        pp = pre(nr, 4 * 64, 2 * REDUCE_SLICES);
+        hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, g->conv1_w, g->conv1_b);
+        CKL("conv1_bwd_kernel");
+    }
+    return 0;
+}
+
 template <typename T>
 static int encoder_backward_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
                               cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready) {
@@ -1296,72 +1394,220 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         }
         T* tmp = cur; cur = nxt; nxt = tmp;
     }
-    // every gradient but the conv stack's is final here (cp_encoder_backward_ev): a data-parallel caller starts summing
-    // them across ranks while the conv backward below still runs
-    if (fc_grads_ready) CK(hipEventRecord(fc_grads_ready, st));
-    // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, cur, nxt, bn_done, stat_rows);
+}
+
+
+// e5m2 tensor -> bf16 in true units (the gradient tap of the tests)
+__global__ __launch_bounds__(256) void dequant5_bf16_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int64_t n4,
+                                                            const Fp8State* __restrict__ st, int t) {
+    const float d = f8_exp2i(-st->e[t]);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[4];
+        f8_unpack4_e5m2(*(const uint32_t*)(in + i * 4), v);
+        *(uint2*)(out + i * 4) = make_uint2(pack2bf(v[0] * d, v[1] * d), pack2bf(v[2] * d, v[3] * d));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// encoder backward, CP_FP8: the fc stack in 8 bits (csrc/fp8.cuh) -- e5m2 gradients between the layers, the saved e4m3
+// activations, W^T as e4m3 -- then the conv stack on the bf16 kernels (fc1's data-gradient launch writes bf16).
+// Same order of work as encoder_backward_t<bf16_t>; CPNATIVE_FP8_BRIDGE keeps the first build's route (expand the saved
+// tensors to bf16, run the bf16 backward) for A/B runs and for the test that compares the two.
+// ---------------------------------------------------------------------------------------
+static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
+                                cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready) {
+    using T = bf16_t;
+    const int64_t N = c->n_windows;
+    const bool drop = c->training && c->dp_emg > 0.f;
+    if (g_sync_fn) return fail(CP_ERR_ARG, "CP_FP8: synchronised BatchNorm is not wired into the 8-bit path");
+    float* partials = (float*)(base + w.partials);
+    float* slabs = (float*)(base + w.slabs);
+    float* coef = (float*)(base + w.coef);
+    float* praw = (float*)(base + w.praw);
+    Fp8State* fs = (Fp8State*)(base + w.f8state);
+    auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
+    const PreReduce pre{partials, (float*)(base + w.partials2), st};
+    auto bwd_finalize = [&](const float* pp, int nr, double count, int l, int C, int nfold, const char* what) -> int {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nr, count, stats(l), coef, g->bn_g[l],
+                           g->bn_b[l], C, nfold, (const float*)nullptr);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail((int)e, what);
+    };
+    auto tap8 = [&](int slot, const uint8_t* src, int t) -> int {          // test aid: the e5m2 gradient expanded into the bf16 tap
+        if (!g_grad_tap) return 0;
+        const size_t slot_bytes = (size_t)N * 768 * 2;
+        if ((size_t)(slot + 1) * slot_bytes > g_grad_tap_bytes) return fail(CP_ERR_ARG, "gradient tap buffer too small");
+        hipLaunchKernelGGL(dequant5_bf16_kernel, dim3(1024), dim3(256), 0, st, src, (bf16_t*)(g_grad_tap + slot * slot_bytes), N * 128, fs, t);
+        CKL("dequant5_bf16_kernel");
+        return 0;
+    };
     {
+        ProfScope ps(CP_K_PREP, st);
+        Transpose8Batch tb{};
+        for (int i = 0; i < CP_N_FC; ++i)
+            tb.job[i] = Transpose8Job{p->fc_w[i], base + w.wfc8t[i], base + w.wsc8t[i], fcK(i), i == 0 ? 1 : 0, F8_T_GRAD + (i + 2)};
+        hipLaunchKernelGGL(transpose_w8_batch_kernel, dim3(12, CP_N_FC), dim3(256), 0, st, tb, (const Fp8State*)fs);
+        hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(64), dim3(256), 0, st, p->last_w, (T*)(base + w.wlast_t), CP_D_E, 512, 64, 0);
+        CKL("transpose kernels (fp8)");
+    }
+    T* dz = (T*)(base + w.dz);
+    uint8_t* cur = base + w.g8[0];
+    uint8_t* nxt = base + w.g8[1];
+    int stat_rows = 0;
+    bool bn_done = false;
+    // ---- projection ------------------------------------------------------------------
+    {
+        ProfScope ps(CP_K_PROJ_BWD, st);
+        float* dzsum = (float*)(base + w.dzsum);
+        const float *s = nullptr, *t = nullptr;
+        if (!drop) {
+            s = stats(8) + 2 * 512; t = stats(8) + 3 * 512;
+            const int gb = grid_rows(N, 256 / (CP_D_E / DT<T>::EPC), 64);
+            hipLaunchKernelGGL((colsum_kernel<T>), dim3(gb), dim3(256), 256 * DT<T>::EPC * 4, st, dz, partials, N, 64, CP_D_E);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(CP_D_E)), dim3(FIN_THREADS), 0, st, partials, gb, CP_D_E, dzsum);
+            CKL("colsum(dz)");
+        }
+        GemmTNArgs ta{};
+        ta.X = dz; ta.ldx = 64; ta.Y = base + w.act8[8]; ta.ldy = 512; ta.slabs = slabs; ta.M = N; ta.P = 64; ta.Q = 512;
+        ta.y_exp = &fs->e[F8_T_ACT + 8];
+        int S;
+        split_rows(N, 128, &S, &ta.rows_per_split);
+        if (drop) {
+            ta.y_scale = stats(8) + 2 * 512; ta.y_shift = stats(8) + 3 * 512;
+            ta.dp_thresh = dp_thresh(c->dp_emg); ta.dp_key = dp_key(c, 8); ta.dp_inv_keep = dp_inv_keep(c->dp_emg); ta.dp_salt = dp_salt(c);
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_BNDROP_F8>(ta, S, st)));
+        } else {
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_F8>(ta, S, st)));
+        }
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
+                           drop ? (float*)nullptr : praw, (const int*)nullptr, (const int*)nullptr);
+        CKL("reduce_slabs(last)");
+        Proj8Args a{};
+        a.A = dz; a.lda = 64; a.W = (const bf16_t*)(base + w.wlast_t); a.K = 64; a.R = base + w.act8[8]; a.C = cur;
+        a.partials = partials; a.st = fs; a.t_r = F8_T_ACT + 8; a.t_out = F8_T_GRAD + 8; a.M = N;
+        int drows = 0;
+        if (drop) {
+            a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c);
+            CK(launch_proj_dgrad8<0>(a, st, &drows));
+            int nr = drows;
+            const float* pp = pre(nr, 2 * 512);
+            if (int e = bwd_finalize(pp, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
+        } else {
+            // no dropout behind fc7: its BatchNorm-backward sums follow from the projection's weight gradient (no N-sized read)
+            hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials, CP_D_E, 512, 0);
+            CKL("bn_bwd_sums_from_wgrad_kernel(last)");
+            if (int e = bwd_finalize(partials, 1, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, fused)")) return e;
+        }
+        a.coef = coef;
+        CK(launch_proj_dgrad8<1>(a, st, &drows));
+        int nr = drows;
+        const float* pp = pre(nr, 512);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[6]);
+        CKL("colsum_finalize_kernel(fc7)");
+        bn_done = true;
+    }
+    // ---- fc7 .. fc1 --------------------------------------------------------------------
+    struct { const uint8_t* X; const uint8_t* Y; int i, tx, ty; } pend{};
+    bool pending = false;
+    T* gconv = (T*)(base + w.gbuf[0]);                       // fc1's data gradient, bf16 [N][768]: what the conv kernels read
+    for (int L = 8; L >= 2; --L) {
+        const int i = L - 2, Lp = L - 1, K = fcK(i);
         if (!bn_done) {
+            // cur = masked dL/d(BN_L output) (F8_T_GB + L): BatchNorm + ReLU backward in place -> dL/d(pre-activation) (F8_T_GRAD + L)
             ProfScope ps(CP_K_BN_BWD, st);
-            int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
-            const float* pp = pre(nr, 2 * 768);
-            if (int e = bwd_finalize(pp, nr, (double)R12, 1, 64, 12, "bn_bwd_finalize_kernel(conv2)")) return e;
-            const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
-            hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
+            int nr = stat_rows;
+            const float* pp = pre(nr, 2 * 512);
+            if (int e = bwd_finalize(pp, nr, (double)N, L, 512, 1, "bn_bwd_finalize_kernel")) return e;
+            const int gb = grid_rows(N, 256 / (512 / 16), 2048);
+            hipLaunchKernelGGL(bn_relu_bwd8_kernel, dim3(gb), dim3(256), 8 * 512 * 4, st, cur, base + w.act8[L], coef, partials, N, 512, fs,
+                               F8_T_GB + L, F8_T_ACT + L, F8_T_GRAD + L);
             nr = gb;
-            pp = pre(nr, 64);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
-            CKL("bn_relu_bwd_kernel(conv2)");
+            pp = pre(nr, 512);
+            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[i]);
+            CKL("bn_relu_bwd8_kernel");
         }
-        if (int e = tap_gradient(1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
-        ConvArgs ca{};
-        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0); ca.gin = cur; ca.n_windows = N;
-        {
-            ProfScope ps(CP_K_CONV2_WGRAD, st);
-            const int64_t strips = (N + CONV_WG_WPB - 1) / CONV_WG_WPB;
-            const int64_t cap = sizeof(T) == 2 ? 512 : 256;      // two blocks per CU (194 registers with the strip prefetch)
-            const int S = (int)(strips < cap ? strips : cap);
-            ca.partials = slabs;
-            hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
-            // up to 512 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
-            // unused tail of the slab buffer), then the scatter kernel walks 32 instead of 512
-            const float* sl = slabs;
-            int ns = S;
-            if (S > 2 * REDUCE_SLICES) {
-                float* folded = slabs + (size_t)S * 64 * 192;
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(64 * 192 / 64, REDUCE_SLICES), dim3(256), 0, st, slabs, S, 64 * 192, folded);
-                sl = folded;
-                ns = REDUCE_SLICES;
+        if (int e = tap8(L, cur, F8_T_GRAD + L)) return e;
+        const bool in_drop = drop && Lp >= 5;
+        const uint8_t* Y = in_drop ? base + w.u8[Lp - 5] : base + w.act8[Lp];
+        const int ty = in_drop ? F8_T_U + (Lp - 5) : F8_T_ACT + Lp, tx = F8_T_GRAD + L;
+        const float* s = in_drop ? nullptr : stats(Lp) + 2 * kLayerC[Lp];
+        const float* t = in_drop ? nullptr : stats(Lp) + 3 * kLayerC[Lp];
+        int S;
+        const bool defer_wgrad = in_drop && (i == 6 || i == 4) && fcK(i - 1) == 512;
+        if (defer_wgrad) {
+            pend.X = cur; pend.Y = Y; pend.i = i; pend.tx = tx; pend.ty = ty;
+            pending = true;
+        } else {
+            GemmTN8Args ta{};
+            ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
+            const int target = pending ? 32 : (K == 512 ? 64 : 40);
+            int64_t rps = (N + target - 1) / target;
+            rps = ((rps + 63) / 64) * 64;
+            ta.rows_per_split = rps;
+            S = (int)((N + rps - 1) / rps);
+            if (pending) { ta.X2 = pend.X; ta.Y2 = pend.Y; ta.slabs2 = slabs + (size_t)32 * 512 * 512; }
+            ta.splits = S;
+            ProfScope ps(CP_K_FC_WGRAD, st);
+            CK(launch_gemm_tn8(ta, st));
+        }
+        if (!defer_wgrad) {
+            ProfScope ps(CP_K_REDUCE_SLABS, st);
+            if (pending) {
+                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
+                                   (const float*)nullptr, (const float*)nullptr, g->fc_b[pend.i], g->fc_w[pend.i], 0, (float*)nullptr,
+                                   (const int*)&fs->e[pend.tx], (const int*)&fs->e[pend.ty]);
+                CKL("reduce_slabs(fc, deferred)");
+                pending = false;
             }
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, sl, ns, 64, 192, 64, (const float*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2, (float*)nullptr);
-            CKL("conv2_wgrad_kernel");
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
+                               i == 0 ? 1 : 0, in_drop ? (float*)nullptr : praw, (const int*)&fs->e[tx], (const int*)&fs->e[ty]);
+            CKL("reduce_slabs(fc)");
+            if (!in_drop) {
+                hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(K / 64, kSumSlices), dim3(256), 0, st, praw, p->fc_w[i], g->fc_b[i],
+                                   partials, 512, K, i == 0 ? 1 : 0);
+                CKL("bn_bwd_sums_from_wgrad_kernel");
+            }
         }
-        conv_dgrad_rows = conv_grid<T>(N);
-        ca.wc = base + w.wc2_d; ca.out = nxt; ca.partials = partials;
-        {
-            ProfScope ps(CP_K_CONV2_DGRAD, st);
-            hipLaunchKernelGGL((conv2_strip_kernel<T, 1>), dim3(conv_dgrad_rows), dim3(256), 0, st, ca);
-            CKL("conv2_strip_kernel<dgrad>");
+        Wsd8Args a{};
+        a.A = cur; a.W = base + w.wfc8t[i]; a.wsc = base + w.wsc8t[i]; a.R = base + w.act8[Lp]; a.partials = partials;
+        a.st = fs; a.t_r = F8_T_ACT + Lp; a.M = N; a.F = K;
+        bn_done = false;
+        if (!in_drop) {
+            const int Cp = kLayerC[Lp], nfold = K / Cp;
+            {
+                ProfScope ps(CP_K_BN_BWD, st);
+                int nr = kSumSlices;
+                const float* pp = pre(nr, 2 * K);
+                if (int e = bwd_finalize(pp, nr, (double)N * nfold, Lp, Cp, nfold, "bn_bwd_finalize_kernel(fused)")) return e;
+            }
+            a.coef = coef; a.coef_mod = Cp;
+            int drows = 0;
+            {
+                ProfScope ps(CP_K_FC_DGRAD_BN, st);
+                if (Lp == 1) { a.C = gconv; a.t_out = -1; CK((launch_gemm_wsd8<0, true>(a, st, &drows))); }
+                else { a.C = nxt; a.t_out = F8_T_GRAD + Lp; CK((launch_gemm_wsd8<0, false>(a, st, &drows))); }
+            }
+            {
+                ProfScope ps(CP_K_BN_BWD, st);
+                int nr = drows * nfold;
+                const float* pp = pre(nr, Cp);
+                float* db = Lp >= 2 ? g->fc_b[i - 1] : g->conv2_b;
+                hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(Cp)), dim3(FIN_THREADS), 0, st, pp, nr, Cp, db);
+                CKL("colsum_finalize_kernel(fused)");
+            }
+            bn_done = true;
+        } else {
+            a.C = nxt; a.t_out = F8_T_GB + Lp;
+            a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c);
+            ProfScope ps(CP_K_FC_DGRAD_STATS, st);
+            int drows = 0;
+            CK((launch_gemm_wsd8<1, false>(a, st, &drows)));
+            stat_rows = drows;
         }
+        uint8_t* tmp = cur; cur = nxt; nxt = tmp;
     }
-    if (int e = tap_gradient(0, nxt, N, 768, sizeof(T), st)) return e;             // dL/d(BN1 output), [w][c]
-    // ---- conv1 -----------------------------------------------------------------------------
-    {
-        ProfScope ps(CP_K_CONV1_BWD, st);
-        int nr = conv_dgrad_rows;
-        const float* pp = pre(nr, 2 * 64);
-        if (int e = bwd_finalize(pp, nr, (double)R12, 0, 64, 1, "bn_bwd_finalize_kernel(conv1)")) return e;
-        constexpr int RPP = 256 / (64 / D::EPC);                      // windows per block and pass
-        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
-        const int gb = (int)((need + passes - 1) / passes);           // every block makes the same number of passes
-        hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, x, p->conv1_w, p->conv1_b, coef, partials, R12);
-        nr = gb;
-        pp = pre(nr, 4 * 64, 2 * REDUCE_SLICES);
-        hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, g->conv1_w, g->conv1_b);
-        CKL("conv1_bwd_kernel");
-    }
-    return 0;
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gconv, (T*)(base + w.gbuf[1]), true, 0);
 }
 
 extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,
@@ -1370,9 +1616,11 @@ extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, 
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !grads) return fail(CP_ERR_ARG, "cp_encoder_backward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
+    if (cfg->dtype == CP_FP8 && !getenv("CPNATIVE_FP8_BRIDGE"))
+        return encoder_backward_fp8(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
     if (cfg->dtype == CP_FP8) {
-        // (bridge, while the 8-bit backward kernels are being built: the e4m3 tensors of the forward pass are expanded to bf16 --
-        //  exactly -- and the bf16 backward kernels run on them)
+        // (bridge = the first build's route, kept for A/B runs and as the test's comparison: the e4m3 tensors of the forward pass are
+        //  expanded to bf16 -- exactly -- and the bf16 backward kernels run on them)
         unsigned char* base = (unsigned char*)ws;
         hipStream_t st = (hipStream_t)stream;
         const Fp8State* fs = (const Fp8State*)(base + w.f8state);

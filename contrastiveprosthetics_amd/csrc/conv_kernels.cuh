@@ -385,8 +385,9 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
     }
     if constexpr (MODE == 0 && sizeof(T) == 2) {
         if (a.out8 != nullptr) {
-            out_max = wave_max(out_max);
-            if ((tid & 63) == 0 && out_max > 0.f) atomicMax(a.out_amax, __float_as_uint(out_max));
+            out_max = wave_max(out_max);               // (fp8.cuh, f8_atomic_amax: the atomic only where it raises the word)
+            if ((tid & 63) == 0 && out_max > 0.f && __float_as_uint(out_max) > __hip_atomic_load(a.out_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(a.out_amax, __float_as_uint(out_max));
         }
     }
 #pragma unroll

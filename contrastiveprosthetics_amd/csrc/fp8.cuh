@@ -92,9 +92,15 @@ __device__ __forceinline__ uint32_t f8_pack4(float a, float b, float c, float d)
     return (uint32_t)p;
 }
 __device__ __forceinline__ float f8_clamp(float v) { return __builtin_amdgcn_fmed3f(v, -F8_E4M3_MAX, F8_E4M3_MAX); }
+// Running maximum of a tensor: one candidate per wave, and the atomic only where it would raise the word -- thousands of waves end at
+// about the same time, and same-address atomics serialise in L2 (the first version, an unconditional atomicMax per wave, made the
+// 8-bit dropout pass 3x slower than the bf16 one).  The word is read past L1 (agent scope); a stale read costs one needless atomic.
 __device__ __forceinline__ void f8_atomic_amax(uint32_t* dst, float m) {
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dst, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        const uint32_t bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -484,4 +490,802 @@ __global__ void dequant8_f32_kernel(const uint8_t* __restrict__ in, float* __res
     const float d = f8_exp2i(-st->e[t]);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = __builtin_amdgcn_cvt_f32_fp8((int)in[i], 0) * d;
+}
+
+// ========================================================================================================================
+// Backward pass in 8 bits.  Gradients between layers are stored as OCP e5m2 (two mantissa bits, 32 binades: the format made for
+// gradients), activations stay e4m3; every product is a block-scaled MFMA with the operand formats mixed per operand
+// (cbsz / blgp), f32 accumulation.  Two kinds of gradient tensor travel through HBM:
+//   F8_T_GRAD + l : dL/d(pre-activation of layer l) -- the weight gradient's X operand and the data gradient's A operand;
+//   F8_T_GB + l   : dL/d(BatchNorm_l output) behind a dropout (masked), rewritten in place into the first kind by bn_relu_bwd8.
+// ========================================================================================================================
+enum { F8_T_GB = 32 };
+
+__device__ __forceinline__ float f8_clamp5(float v) { return __builtin_amdgcn_fmed3f(v, -F8_E5M2_MAX, F8_E5M2_MAX); }
+__device__ __forceinline__ uint32_t f8_pack4_e5m2(float a, float b, float c, float d) {
+    int p = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    p = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, p, true);
+    return (uint32_t)p;
+}
+__device__ __forceinline__ void f8_unpack4_e5m2(uint32_t w, float* o) {
+    const auto lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, true);
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// W^T for the data gradients, quantised to e4m3 with one power-of-two scale per row of W^T (= input feature k of the layer):
+//   out_w[k'][j] = e4m3(W[j][k] 2^ek),  out_sc[k'] = 127 - ek - eg   (eg = scale exponent of the gradient the launch will read)
+// so that the accumulators of the data-gradient launch are in TRUE units.  One block per 64 rows of W^T; two sweeps over its
+// 512 x 64 slice of W (the second hits L2).  mode 1 (fc1): k' = w*64 + c of k = c*12 + w.
+// ------------------------------------------------------------------------------------------------------------------------
+struct Transpose8Job { const float* W; uint8_t* out_w; uint8_t* out_sc; int K, mode, t_grad; };
+struct Transpose8Batch { Transpose8Job job[CP_N_FC]; };
+__global__ __launch_bounds__(256) void transpose_w8_batch_kernel(Transpose8Batch b, const Fp8State* __restrict__ st) {
+    __shared__ float cmax[4][64];
+    __shared__ uint8_t tile[64][64 + 4];
+    const Transpose8Job j = b.job[blockIdx.y];
+    const int k0 = blockIdx.x * 64;
+    if (k0 >= j.K) return;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int kp = k0 + lane;                                          // row of W^T in the internal order
+    const int k = j.mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;       // column of W
+    float am = 0.f;
+    for (int jj = grp; jj < 512; jj += 4) am = fmaxf(am, fabsf(j.W[(int64_t)jj * j.K + k]));
+    cmax[grp][lane] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(cmax[0][lane], cmax[1][lane]), fmaxf(cmax[2][lane], cmax[3][lane]));
+    const int ek = f8_fit_exp(am, F8_E4M3_MAX);
+    const float sc = f8_exp2i(ek);
+    if (grp == 0) {
+        int sb = 127 - ek - st->e[j.t_grad];
+        j.out_sc[kp] = (uint8_t)(sb < 1 ? 1 : (sb > 254 ? 254 : sb));
+    }
+    for (int j0 = 0; j0 < 512; j0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = grp + 4 * r;
+            const int p = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(j.W[(int64_t)(j0 + jj) * j.K + k] * sc), 0.f, 0, false);
+            tile[lane][jj] = (uint8_t)(p & 255);                       // [k row][j]
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = grp + 4 * r;
+            j.out_w[(int64_t)(k0 + kk) * 512 + j0 + lane] = tile[kk][lane];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Data gradient of an fc layer:  G_out[m][k] = epilogue( sum_f G[m][f] W[f][k] ),  G e5m2 [M][512], W^T e4m3 row-scaled (true-unit
+// accumulators), weight-stationary as gemm_ws8_kernel with 32-row tiles and four A buffers; the wave fetches the 32 x 64 sub-tile
+// of the saved e4m3 activation R it needs (2 KiB, two LDS-DMA instructions) during the tile's own k loop and reads it back, in
+// the accumulator layout, in that tile's epilogue one k loop later (its own vmcnt is the only ordering).
+//   MODE 0: BatchNorm + ReLU backward of the layer below in the epilogue (coef), output = dL/d(its pre-activation), column sums =
+//           its bias gradient.  OUT_BF16: output stored as bf16 in true units (fc1's launch: the conv kernels read 16-bit gradients).
+//   MODE 1: behind a dropout: the forward pass's mask, output = masked dL/d(BatchNorm output) (F8_T_GB), the two BatchNorm-backward
+//           sums against R.
+// LDS image of R per wave and buffer: row r at r*64, its four 16-byte chunks XORed with (r >> 2) & 3 (rows r, r+4, r+8, r+12 of a
+// ds_read_b32 share their bank group otherwise).
+// ------------------------------------------------------------------------------------------------------------------------
+struct Wsd8Args {
+    const uint8_t* A;       // [M][512] e5m2 gradient
+    const uint8_t* W;       // [F][512] e4m3 = W^T of the layer, row-scaled (transpose_w8_batch_kernel)
+    const uint8_t* wsc;     // [F]
+    const uint8_t* R;       // [M][F] e4m3 saved activation of the layer below
+    void* C;                // [M][F] e5m2 (or bf16 with OUT_BF16)
+    float* partials;        // MODE 0: [workers][F] column sums (true units);  MODE 1: [workers][2][F]
+    const float* coef;      // MODE 0: [3][coef_mod]
+    int coef_mod;
+    Fp8State* st;
+    int t_r, t_out;         // scale-table ids of R and of the output (t_out < 0 with OUT_BF16)
+    int64_t M;
+    int F;
+    uint32_t dp_thresh, dp_key;
+    const uint32_t* dp_salt;
+    float dp_inv_keep;
+};
+
+template <int FT>
+__device__ __forceinline__ f32x4_t mx_mfma_g(const i32x8_t& w, const i32x8_t& g, const f32x4_t& c, int wscale) {
+    // A = weights (e4m3), B = gradient rows (e5m2)
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, g, c, 0, 1, FT, wscale, 0, 127);
+}
+
+#define WSD8_RT 32
+template <int MODE, bool OUT_BF16>
+__global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
+    constexpr bool STATS = MODE == 1;
+    constexpr int K = 512, KB = K / 128, RT = WSD8_RT, ST = RT / 16, NBUF = 4, AHEAD = NBUF - 1;
+    constexpr int TILE_BYTES = RT * K, UPW = TILE_BYTES / 1024 / 4, CPR = K / 16, R_BYTES = RT * 64, RU = R_BYTES / 1024;
+    constexpr int R_OFF = NBUF * TILE_BYTES;
+    static_assert((AHEAD - 1) * UPW + AHEAD * (ST + RU) <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R_OFF + 4 * 2 * R_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, q4 = lane >> 4;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nfb = a.F >> 8;
+    const int nwk = 32 / nfb;
+    const int fb = j % nfb, wkr = j / nfb;
+    const int64_t tiles = (a.M + RT - 1) / RT;
+    const int first = wkr * 8 + xcd, stride = nwk * 8;
+    const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
+    if (ntile == 0) return;
+    const int f0 = fb * 256 + wave * 64;
+    const uint32_t dkey = (STATS && a.dp_thresh != 0) ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
+    const int e_r = a.st->e[a.t_r], e_o = OUT_BF16 ? 0 : a.st->e[a.t_out];
+    const float so = f8_exp2i(e_o);
+
+    // MODE 0: BatchNorm-backward coefficients of this lane's 16 features, with the scales folded in: the epilogue's result is the
+    // output in STORED units:  y 2^eo = ca 2^eo acc + cb 2^(eo - er) r8 + cz 2^eo
+    float4 cfa[STATS ? 1 : 4], cfb[STATS ? 1 : 4], cfz[STATS ? 1 : 4];
+    if constexpr (!STATS) {
+        const float sr = f8_exp2i(e_o - e_r);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            float v[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[c][e] = a.coef[c * a.coef_mod + (f0 + ft * 16 + 4 * q4 + e) % a.coef_mod];
+            cfa[ft] = make_float4(v[0][0] * so, v[0][1] * so, v[0][2] * so, v[0][3] * so);
+            cfb[ft] = make_float4(v[1][0] * sr, v[1][1] * sr, v[1][2] * sr, v[1][3] * sr);
+            cfz[ft] = make_float4(v[2][0] * so, v[2][1] * so, v[2][2] * so, v[2][3] * so);
+        }
+    }
+
+    i32x8_t wreg[4][KB];
+    int wscale = 0;
+    {
+        const uint8_t* Wg = a.W + (int64_t)(f0 + s16) * K + 32 * q4;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const i32x4_t lo = *(const i32x4_t*)(Wg + (int64_t)ft * 16 * K + kb * 128);
+                const i32x4_t hi = *(const i32x4_t*)(Wg + (int64_t)ft * 16 * K + kb * 128 + 16);
+                wreg[ft][kb] = (i32x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            wscale |= (int)a.wsc[f0 + ft * 16 + s16] << (8 * ft);
+        }
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+a"(wreg[ft][kb]));
+    }
+
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const uint64_t a_base = (uint64_t)(uintptr_t)a.A, r_base = (uint64_t)(uintptr_t)a.R;
+    const u32x4_t a_rsrc = {(uint32_t)a_base, (uint32_t)(a_base >> 32) & 0xFFFFu, (uint32_t)(a.M * K), 0x00020000u};
+    const u32x4_t r_rsrc = {(uint32_t)r_base, (uint32_t)(r_base >> 32) & 0xFFFFu, (uint32_t)(a.M * a.F), 0x00020000u};
+    uint32_t fsrc[UPW];
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+        const int g = (wave * UPW + q) * 64 + lane, row = g / CPR, pc = g % CPR;
+        fsrc[q] = (uint32_t)(row * K + (((pc & ~15) | ((pc ^ row) & 15)) << 4));
+    }
+    auto fetch_unit = [&](uint32_t tile_soff, int buf, int q) {
+        bufl16_lds(a_rsrc, fsrc[q], tile_soff, lds0 + buf * TILE_BYTES + (wave * UPW + q) * 1024);
+    };
+    // R: unit k = rows 16k .. 16k+15 of the tile x this wave's 64 bytes; lane l = row 16k + (l >> 2), physical chunk l & 3
+    uint32_t rsrc_l[RU];
+#pragma unroll
+    for (int k = 0; k < RU; ++k) {
+        const int row = 16 * k + (lane >> 2);
+        rsrc_l[k] = (uint32_t)(row * a.F + f0 + (((lane & 3) ^ ((row >> 2) & 3)) << 4));
+    }
+    auto fetch_r = [&](uint32_t tile_soff, int buf, int k) {
+        bufl16_lds(r_rsrc, rsrc_l[k], tile_soff, lds0 + R_OFF + (wave * 2 + buf) * R_BYTES + k * 1024);
+    };
+    auto row0 = [&](int ti) -> int64_t { return ((int64_t)ti * stride + first) * RT; };
+    auto tile_soff = [&](int ti) -> uint32_t { return ti < ntile ? (uint32_t)(row0(ti) * K) : 0xFFF00000u; };
+
+    float s1[16], s2[STATS ? 16 : 1], amax = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s1[p] = 0.f;
+#pragma unroll
+    for (int p = 0; p < (STATS ? 16 : 1); ++p) s2[p] = 0.f;
+    constexpr int OB = OUT_BF16 ? 2 : 1;                                     // bytes per output element
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * a.F * OB), 0x00020000);
+    // e5m2: after the 4-lane transpose a lane owns features q4*16 .. +15 of its sample (16 bytes); bf16: features foff .. foff + 7 of
+    // each 32-feature pair after one permlane16 swap (gemm_ws16_kernel)
+    const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);
+    const uint32_t c_lane = OUT_BF16 ? (uint32_t)(s16 * a.F + f0 + foff) * 2 : (uint32_t)(s16 * a.F + f0 + q4 * 16);
+
+    auto epi_st = [&](f32x4_t (&old)[4][ST], const unsigned char* Rw, int st, uint32_t s_old, bool live, int64_t m_old) {
+        const int row = st * 16 + s16;
+        const int rsw = (row >> 2) & 3;
+        uint32_t d[4];
+        uint2 pk[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            float rv[4];
+            f8_unpack4(*(const uint32_t*)(Rw + row * 64 + ((ft ^ rsw) << 4) + 4 * q4), rv);
+            float y[4] = {old[ft][st][0], old[ft][st][1], old[ft][st][2], old[ft][st][3]};
+            if constexpr (!STATS) {
+                const float4 ca = cfa[ft], cb = cfb[ft], cz = cfz[ft];
+                y[0] = rv[0] > 0.f ? fmaf(ca.x, y[0], fmaf(cb.x, rv[0], cz.x)) : 0.f;
+                y[1] = rv[1] > 0.f ? fmaf(ca.y, y[1], fmaf(cb.y, rv[1], cz.y)) : 0.f;
+                y[2] = rv[2] > 0.f ? fmaf(ca.z, y[2], fmaf(cb.z, rv[2], cz.z)) : 0.f;
+                y[3] = rv[3] > 0.f ? fmaf(ca.w, y[3], fmaf(cb.w, rv[3], cz.w)) : 0.f;
+            } else {
+                float k0 = so, k1 = so, k2 = so, k3 = so;
+                if (a.dp_thresh != 0) {
+                    const uint32_t col = (uint32_t)(f0 + ft * 16 + 4 * q4);
+                    const uint32_t m = (uint32_t)(m_old + row);
+                    const uint32_t p0 = dropout_pair(dkey, m, (uint32_t)a.F, col);
+                    const uint32_t p1 = dropout_pair(dkey, m, (uint32_t)a.F, col + 2);
+                    k0 = dropout_scale(p0, 0, a.dp_thresh, a.dp_inv_keep) * so;
+                    k1 = dropout_scale(p0, 1, a.dp_thresh, a.dp_inv_keep) * so;
+                    k2 = dropout_scale(p1, 0, a.dp_thresh, a.dp_inv_keep) * so;
+                    k3 = dropout_scale(p1, 1, a.dp_thresh, a.dp_inv_keep) * so;
+                }
+                y[0] *= k0; y[1] *= k1; y[2] *= k2; y[3] *= k3;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float w = live ? y[e] : 0.f;
+                s1[ft * 4 + e] += w;
+                if constexpr (STATS) s2[ft * 4 + e] = fmaf(w, rv[e], s2[ft * 4 + e]);
+            }
+            if constexpr (OUT_BF16) {
+                pk[ft].x = cvt_pk_bf16<false>(y[0], y[1]);
+                pk[ft].y = cvt_pk_bf16<false>(y[2], y[3]);
+            } else {
+                amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
+                amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
+                d[ft] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+            }
+        }
+        if constexpr (OUT_BF16) {
+#pragma unroll
+            for (int fp = 0; fp < 2; ++fp) {
+                const auto sx = __builtin_amdgcn_permlane16_swap(pk[2 * fp].x, pk[2 * fp + 1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(pk[2 * fp].y, pk[2 * fp + 1].y, false, false);
+                const u32x4_t c = {sx[0], sy[0], sx[1], sy[1]};
+                store_b128_settled(c, c_rsrc, c_lane, (s_old + (uint32_t)(st * 16 * a.F + fp * 32)) * 2, 0);
+            }
+        } else {
+            { const auto x = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false); d[0] = x[0]; d[2] = x[1]; }
+            { const auto x = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false); d[1] = x[0]; d[3] = x[1]; }
+            { const auto x = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false); d[0] = x[0]; d[1] = x[1]; }
+            { const auto x = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false); d[2] = x[0]; d[3] = x[1]; }
+            const u32x4_t c = {d[0], d[1], d[2], d[3]};
+            store_b128_settled(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.F), 0);
+        }
+    };
+    constexpr int NST = OUT_BF16 ? 2 * ST : ST;                              // stores per epilogue
+
+    auto load_frag = [&](const unsigned char* At, int kb, int st) -> i32x8_t {
+        const int c0 = kb * 8 + q4 * 2;
+        const i32x4_t lo = *(const i32x4_t*)(At + st * 16 * K + ((c0 ^ s16) << 4));
+        const i32x4_t hi = *(const i32x4_t*)(At + st * 16 * K + (((c0 + 1) ^ s16) << 4));
+        return (i32x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    auto step = [&](f32x4_t (&acc)[4][ST], f32x4_t (&old)[4][ST], int ti, auto with_epi_tag, int64_t m_old) {
+        constexpr bool WITH_EPI = decltype(with_epi_tag)::value;
+        const int buf = ti % NBUF;
+        const uint32_t next_soff = tile_soff(ti + AHEAD);
+        const int nbuf = (ti + AHEAD) % NBUF;
+        const uint32_t r_soff = (uint32_t)(row0(ti) * a.F);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int st = 0; st < ST; ++st) acc[ft][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const unsigned char* At = smem + buf * TILE_BYTES + s16 * K;
+        i32x8_t fa[2][ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) fa[0][st] = load_frag(At, 0, st);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (kb + 1 < KB) {
+#pragma unroll
+                for (int st = 0; st < ST; ++st) fa[(kb + 1) & 1][st] = load_frag(At, kb + 1, st);
+            }
+#pragma unroll
+            for (int st = 0; st < ST; ++st) {
+                const int slot = kb * ST + st;
+                if (slot < UPW) fetch_unit(next_soff, nbuf, slot);
+                else if (slot < UPW + RU) fetch_r(r_soff, ti & 1, slot - UPW);
+                const i32x8_t& x = fa[kb & 1][st];
+                acc[0][st] = mx_mfma_g<0>(wreg[0][kb], x, acc[0][st], wscale);
+                acc[1][st] = mx_mfma_g<1>(wreg[1][kb], x, acc[1][st], wscale);
+                acc[2][st] = mx_mfma_g<2>(wreg[2][kb], x, acc[2][st], wscale);
+                acc[3][st] = mx_mfma_g<3>(wreg[3][kb], x, acc[3][st], wscale);
+            }
+        }
+        // Everything this wave needs next has landed once its operations older than this tile's are done: the A fetches of tile
+        // ti + 1 and -- for the epilogue below -- the R sub-tile of tile ti - 1.  Younger than those: the previous epilogue's stores
+        // (none in the first two tiles), this tile's A fetches and R fetches.
+        const int ne = ti < 2 ? 0 : 1;
+        if (ti == 0) wait_vmcnt<(AHEAD - 1) * UPW + RU>();                      // (tiles 2, 3 and R(0) may fly; tile 1 has landed)
+        else if (ne == 0) wait_vmcnt<UPW + RU>();
+        else wait_vmcnt<NST + UPW + RU>();
+        if constexpr (WITH_EPI) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* Rw = smem + R_OFF + (wave * 2 + ((ti - 1) & 1)) * R_BYTES;
+            const uint32_t s_old = (uint32_t)(m_old * a.F);
+#pragma unroll
+            for (int st = 0; st < ST; ++st) epi_st(old, Rw, st, s_old, true, m_old);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    auto drain = [&](f32x4_t (&old)[4][ST], int ti, int64_t m_old) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned char* Rw = smem + R_OFF + (wave * 2 + (ti & 1)) * R_BYTES;
+        const uint32_t s_old = (uint32_t)(m_old * a.F);
+#pragma unroll
+        for (int st = 0; st < ST; ++st) epi_st(old, Rw, st, s_old, m_old + st * 16 + s16 < a.M, m_old);
+    };
+
+    f32x4_t accA[4][ST], accB[4][ST];
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) {
+        const uint32_t so_ = tile_soff(t);
+#pragma unroll
+        for (int q = 0; q < UPW; ++q) fetch_unit(so_, t, q);
+    }
+    wait_vmcnt<(AHEAD - 1) * UPW>();
+    __syncthreads();
+    step(accA, accB, 0, std::false_type{}, 0);
+    int ti = 1;
+    while (ti + 1 < ntile) {
+        step(accB, accA, ti, std::true_type{}, row0(ti - 1));
+        step(accA, accB, ti + 1, std::true_type{}, row0(ti));
+        ti += 2;
+    }
+    if (ti < ntile) {
+        step(accB, accA, ti, std::true_type{}, row0(ti - 1));
+        drain(accB, ti, row0(ti));
+    } else {
+        drain(accA, ntile - 1, row0(ntile - 1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // column sums: stored units -> true units
+    const float u1 = f8_exp2i(-e_o), u2 = f8_exp2i(-e_o - e_r);
+    float r1[2], r2[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        float v1[8], v2[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { v1[p] = s1[hh * 8 + p]; v2[p] = STATS ? s2[hh * 8 + p] : 0.f; }
+        r1[hh] = row16_fold8(v1, lane) * u1;
+        r2[hh] = STATS ? row16_fold8(v2, lane) * u2 : 0.f;
+    }
+    if (s16 < 8) {
+        const int64_t prow = (int64_t)wkr * 8 + xcd;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int idx = hh * 8 + s16, f = f0 + (idx >> 2) * 16 + 4 * q4 + (idx & 3);
+            if constexpr (STATS) {
+                a.partials[(prow * 2 + 0) * a.F + f] = r1[hh];
+                a.partials[(prow * 2 + 1) * a.F + f] = r2[hh];
+            } else {
+                a.partials[prow * a.F + f] = r1[hh];
+            }
+        }
+    }
+    if constexpr (!OUT_BF16) f8_atomic_amax(&a.st->amax[a.t_out], amax);
+}
+
+template <int MODE, bool OUT_BF16>
+static inline hipError_t launch_gemm_wsd8(const Wsd8Args& a, hipStream_t st, int* stat_rows) {
+    if ((a.F & 255) || a.F > 768 || a.M <= 0 || (uint64_t)a.M * a.F >= 0xFFF00000ull || !a.R || (MODE == 0 && !a.coef)) return hipErrorInvalidValue;
+    const int nwk = 32 / (a.F >> 8);
+    const int64_t tiles = (a.M + WSD8_RT - 1) / WSD8_RT, workers = (int64_t)nwk * 8;
+    if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
+    hipLaunchKernelGGL((gemm_wsd8_kernel<MODE, OUT_BF16>), dim3(256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of an fc layer in 8 bits:  P[p][q] = sum_m X[m][p] Y[m][q],  X = dL/d(pre-activation) e5m2 [M][512],
+// Y = the layer's input e4m3 [M][Q] (saved activation or dropout output), on v_mfma_scale_f32_32x32x64_f8f6f4 (A = X e5m2,
+// B = Y e4m3, scales 2^0: the product comes out in stored units and reduce_slabs_kernel divides the two tensor scales out).
+// Same shape as gemm_tn256_kernel: 256 x 256 output tile per block, 8 waves of 128(p) x 64(q), the row axis split over blocks
+// (one f32 slab per split), a ring of 4 stages filled by LDS-DMA with counted vmcnt.  What one-byte operands change:
+//   * a stage is 64 rows x 256 bytes per operand (16 KiB, as before) but feeds 8 MFMAs of 64 samples per wave instead of 2 x 8 of 16;
+//   * fragments (32 samples of one column per lane) are four ds_read_b64_tr_b8 (8 rows x 16 byte-columns per 16 lanes each);
+//   * rows past the end of the tensors are ZERO-filled by the buffer bounds check of the LDS-DMA (rows_per_split is a multiple
+//     of 64, so only the last stage of the last split is ragged): no clamping, no masking of fragments.
+// LDS image of an operand stage: [64 rows][256 B]; the 16-byte chunk index of a row is XORed with 2 * (row & 7): the 8 rows of a
+// transposed-read block and the two column blocks of a 32-lane half then fall on 16 different chunk positions.
+// ------------------------------------------------------------------------------------------------------------------------
+struct GemmTN8Args {
+    const uint8_t* X;   // [M][ldx] e5m2
+    const uint8_t* Y;   // [M][ldy] e4m3
+    float* slabs;       // [splits][P][Q]
+    int64_t M;
+    int64_t rows_per_split;   // multiple of 64
+    int ldx, ldy, P, Q, splits;
+    const uint8_t* X2;  // optional second problem of the same shape (gemm_tn256_kernel)
+    const uint8_t* Y2;
+    float* slabs2;
+};
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+
+// fragment = samples 32*(lane >> 5) .. +31 of column col0 + (lane & 31) of a stage image
+__device__ __forceinline__ i32x8_t tn8_frag(const unsigned char* tile, int col0, int lane) {
+    const int g16 = lane >> 4, li = lane & 15, q = li >> 1, p = li & 1;
+    const int row = 32 * (g16 >> 1) + q;                                // + 8 * read index (row & 7 = q for every read)
+    const int lc = (col0 >> 4) + (g16 & 1);
+    const unsigned char* ptr = tile + row * 256 + ((lc ^ (2 * q)) << 4) + 8 * p;
+    i32x8_t f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const i32x2_t v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2_t*)(ptr + r * 8 * 256));
+        f[2 * r] = v[0];
+        f[2 * r + 1] = v[1];
+    }
+    return f;
+}
+
+#define TN8_STAGES 4
+__global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN8Args a) {
+    constexpr int OP_BYTES = 64 * 256, STAGE = 2 * OP_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TN8_STAGES * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 2, wq = wave & 3;
+    const int tiles_q = a.Q / 256, ntiles = (a.P / 256) * tiles_q;
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    const int per_problem = ntiles * ((a.splits + 7) / 8);
+    const bool second = j >= per_problem;
+    if (second) j -= per_problem;
+    const uint8_t* Xg = second ? a.X2 : a.X;
+    const uint8_t* Yg = second ? a.Y2 : a.Y;
+    const int tile = j % ntiles;
+    const int split = (j / ntiles) * 8 + xcd;
+    if (split >= a.splits) return;
+    const int p0 = (tile / tiles_q) * 256, q0 = (tile % tiles_q) * 256;
+    const int64_t mb = (int64_t)split * a.rows_per_split;
+    int64_t me = mb + a.rows_per_split;
+    if (me > a.M) me = a.M;
+    const int nsteps = (int)((me - mb + 63) / 64);
+
+    const uint64_t x_base = (uint64_t)(uintptr_t)Xg, y_base = (uint64_t)(uintptr_t)Yg;
+    const u32x4_t x_rsrc = {(uint32_t)x_base, (uint32_t)(x_base >> 32) & 0xFFFFu, (uint32_t)(a.M * a.ldx), 0x00020000u};
+    const u32x4_t y_rsrc = {(uint32_t)y_base, (uint32_t)(y_base >> 32) & 0xFFFFu, (uint32_t)(a.M * a.ldy), 0x00020000u};
+    // a stage holds 64 rows x 256 B per operand = 16 LDS-DMA instructions of 4 rows; each of the 8 waves issues 2 per operand
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    uint32_t xoff[2], yoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int inst = wave * 2 + i, row = inst * 4 + (lane >> 4), pc = lane & 15;
+        const int lc = pc ^ (2 * (row & 7));
+        xoff[i] = (uint32_t)(row * a.ldx + p0 + lc * 16);
+        yoff[i] = (uint32_t)(row * a.ldy + q0 + lc * 16);
+    }
+    auto stage = [&](int slot, int step) {
+        const int64_t ms = mb + (int64_t)step * 64;
+        const uint32_t Xs = lds0 + slot * STAGE, Ys = Xs + OP_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // (the whole row offset in the per-lane part: the bounds check that zero-fills rows past the end is on it)
+            bufl16_lds(x_rsrc, xoff[i] + (uint32_t)(ms * a.ldx), 0u, Xs + (wave * 2 + i) * 1024);
+            bufl16_lds(y_rsrc, yoff[i] + (uint32_t)(ms * a.ldy), 0u, Ys + (wave * 2 + i) * 1024);
+        }
+    };
+    auto wait_and_stage = [&](int step) {
+        const int ahead = (nsteps - 1 - step) < (TN8_STAGES - 2) ? (nsteps - 1 - step) : (TN8_STAGES - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (step + TN8_STAGES - 1 < nsteps) stage((step + TN8_STAGES - 1) % TN8_STAGES, step + TN8_STAGES - 1);
+    };
+#pragma unroll
+    for (int s = 0; s < TN8_STAGES - 1; ++s)
+        if (s < nsteps) stage(s, s);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][jj][g] = 0.f;
+    for (int step = 0; step < nsteps; ++step) {
+        wait_and_stage(step);
+        const unsigned char* Xs = smem + (step % TN8_STAGES) * STAGE;
+        const unsigned char* Ys = Xs + OP_BYTES;
+        i32x8_t fx[4], fy[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fx[i] = tn8_frag(Xs, wp * 128 + i * 32, lane);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) fy[jj] = tn8_frag(Ys, wq * 64 + jj * 32, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fx[i], fy[jj], acc[i][jj], 1, 0, 0, 127, 0, 127);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    float* slab = (second ? a.slabs2 : a.slabs) + (int64_t)split * a.P * a.Q;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int q = q0 + wq * 64 + jj * 32 + r;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int p = p0 + wp * 128 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                slab[(int64_t)p * a.Q + q] = acc[i][jj][g];
+            }
+        }
+}
+
+static inline hipError_t launch_gemm_tn8(const GemmTN8Args& a, hipStream_t st) {
+    if ((a.P & 255) || (a.Q & 255) || (a.rows_per_split & 63) || (uint64_t)a.M * (a.ldx > a.ldy ? a.ldx : a.ldy) >= 0xFFF00000ull) return hipErrorInvalidValue;
+    const int ntiles = (a.P / 256) * (a.Q / 256);
+    const int groups = (a.splits + 7) / 8;
+    const int problems = a.X2 ? 2 : 1;
+    hipLaunchKernelGGL(gemm_tn8_kernel, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// BatchNorm + ReLU backward in place behind a dropout:  g (e5m2, F8_T_GB + l, masked dL/d(BN_l output))  ->
+// dL/d(pre-activation_l) = [r > 0] (ca g + cb r + cz)  (e5m2, F8_T_GRAD + l), r = the saved e4m3 activation; per-block column
+// sums of the result (the bias gradient), its maximum tracked.  A thread keeps one 16-byte column chunk (16 features).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_relu_bwd8_kernel(uint8_t* __restrict__ g, const uint8_t* __restrict__ r, const float* __restrict__ coef,
+                                                           float* __restrict__ partials, int64_t rows, int C, Fp8State* __restrict__ st,
+                                                           int t_in, int t_r, int t_out) {
+    extern __shared__ float dyn_red[];                  // [rpp][C]
+    const int cpr = C / 16, rpp = 256 / cpr;
+    const int tid = threadIdx.x, cc = tid % cpr, rr = tid / cpr;
+    const int e_in = st->e[t_in], e_r = st->e[t_r], e_o = st->e[t_out];
+    const float ka = f8_exp2i(e_o - e_in), kb = f8_exp2i(e_o - e_r), kz = f8_exp2i(e_o);
+    float ca[16], cb[16], cz[16], sum[16], amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        ca[e] = coef[cc * 16 + e] * ka;
+        cb[e] = coef[C + cc * 16 + e] * kb;
+        cz[e] = coef[2 * C + cc * 16 + e] * kz;
+        sum[e] = 0.f;
+    }
+    auto apply = [&](const uint4& gq, const uint4& rq, int64_t m) {
+        const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, rw[4] = {rq.x, rq.y, rq.z, rq.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float gv[4], rv[4], y[4];
+            f8_unpack4_e5m2(gw[q], gv);
+            f8_unpack4(rw[q], rv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = rv[e] > 0.f ? fmaf(ca[4 * q + e], gv[e], fmaf(cb[4 * q + e], rv[e], cz[4 * q + e])) : 0.f;
+                sum[4 * q + e] += y[e];
+            }
+            amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
+            amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
+            o[q] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+        }
+        *(uint4*)(g + m * C + cc * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    const int64_t step = (int64_t)gridDim.x * rpp;
+    int64_t m = (int64_t)blockIdx.x * rpp + rr;
+    for (; m + step < rows; m += 2 * step) {
+        const uint4 g0 = *(const uint4*)(g + m * C + cc * 16), r0 = *(const uint4*)(r + m * C + cc * 16);
+        const uint4 g1 = *(const uint4*)(g + (m + step) * C + cc * 16), r1 = *(const uint4*)(r + (m + step) * C + cc * 16);
+        apply(g0, r0, m);
+        apply(g1, r1, m + step);
+    }
+    if (m < rows) apply(*(const uint4*)(g + m * C + cc * 16), *(const uint4*)(r + m * C + cc * 16), m);
+    const float un = f8_exp2i(-e_o);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dyn_red[rr * C + cc * 16 + e] = sum[e] * un;
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int q = 0; q < rpp; ++q) s += dyn_red[q * C + c];
+        partials[(int64_t)blockIdx.x * C + c] = s;
+    }
+    f8_atomic_amax(&st->amax[t_out], amax);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The projection's data gradient behind fc7's dropout, 8-bit form of proj_dgrad_kernel (gemm_ws.cuh): g = mask (dz W) / (1 - p) is a
+// rank-16 product, computed TWICE.  PASS 0: the two BatchNorm-backward sums of g against the saved e4m3 activation R, nothing
+// stored.  PASS 1 (coefficients final): g again, r > 0 ? ca g + cb r + cz : 0, stored as e5m2 (F8_T_GRAD + 8), column sums = fc7's
+// bias gradient.  dz stays bf16 (16 live columns, [M][lda]); W = last_w^T in bf16 [512][K].
+// ------------------------------------------------------------------------------------------------------------------------
+struct Proj8Args {
+    const bf16_t* A;        // dz [M][lda]
+    const bf16_t* W;        // [512][K] bf16 (K >= 16: the first 16 columns are read)
+    const uint8_t* R;       // [M][512] e4m3
+    uint8_t* C;             // [M][512] e5m2 (PASS 1)
+    float* partials;
+    const float* coef;      // PASS 1: [3][512]
+    Fp8State* st;
+    int t_r, t_out;
+    int64_t M;
+    int lda, K;
+    uint32_t dp_thresh, dp_key;
+    const uint32_t* dp_salt;
+    float dp_inv_keep;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(256, 2) void proj_dgrad8_kernel(Proj8Args a) {
+    constexpr int RT = 32, ST = RT / 16, R_BYTES = RT * 64, F = 512;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 2 * R_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, q4 = lane >> 4;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nfb = F >> 8;
+    const int nwk = (gridDim.x >> 3) / nfb;
+    const int fb = j % nfb, wkr = j / nfb;
+    const int64_t tiles = (a.M + RT - 1) / RT;
+    const int first = wkr * 8 + xcd, stride = nwk * 8;
+    const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
+    if (ntile == 0) return;
+    const int f0 = fb * 256 + wave * 64;
+    const uint32_t dkey = a.dp_thresh != 0 ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
+    const int e_r = a.st->e[a.t_r], e_o = PASS == 1 ? a.st->e[a.t_out] : 0;
+
+    float4 cfa[PASS == 1 ? 4 : 1], cfb[PASS == 1 ? 4 : 1], cfz[PASS == 1 ? 4 : 1];
+    if constexpr (PASS == 1) {
+        const float so = f8_exp2i(e_o), sr = f8_exp2i(e_o - e_r);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            float v[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[c][e] = a.coef[c * F + f0 + ft * 16 + 4 * q4 + e];
+            cfa[ft] = make_float4(v[0][0] * so, v[0][1] * so, v[0][2] * so, v[0][3] * so);
+            cfb[ft] = make_float4(v[1][0] * sr, v[1][1] * sr, v[1][2] * sr, v[1][3] * sr);
+            cfz[ft] = make_float4(v[2][0] * so, v[2][1] * so, v[2][2] * so, v[2][3] * so);
+        }
+    }
+
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    s16x4_t wfrag[4];                                                        // W[f0 + ft*16 + s16][4*q4 .. +3]
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) wfrag[ft] = *(const s16x4_t*)(a.W + (int64_t)(f0 + ft * 16 + s16) * a.K + 4 * q4);
+
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const uint64_t r_base = (uint64_t)(uintptr_t)a.R;
+    const u32x4_t r_rsrc = {(uint32_t)r_base, (uint32_t)(r_base >> 32) & 0xFFFFu, (uint32_t)(a.M * F), 0x00020000u};
+    auto fetch_r = [&](int64_t m0, int buf) {
+#pragma unroll
+        for (int k = 0; k < R_BYTES / 1024; ++k) {
+            const int row = 16 * k + (lane >> 2);
+            bufl16_lds(r_rsrc, (uint32_t)((m0 + row) * F + f0 + (((lane & 3) ^ ((row >> 2) & 3)) << 4)), 0u, lds0 + (wave * 2 + buf) * R_BYTES + k * 1024);
+        }
+    };
+    auto row0 = [&](int ti) -> int64_t { return ((int64_t)ti * stride + first) * RT; };
+    auto load_dz = [&](int64_t m0, s16x4_t (&d)[ST]) {
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+            int64_t m = m0 + st * 16 + s16;
+            if (m >= a.M) m = a.M - 1;
+            d[st] = *(const s16x4_t*)(a.A + m * a.lda + 4 * q4);
+        }
+    };
+
+    float s1[16], s2[PASS == 0 ? 16 : 1], amax = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s1[p] = 0.f;
+#pragma unroll
+    for (int p = 0; p < (PASS == 0 ? 16 : 1); ++p) s2[p] = 0.f;
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * F), 0x00020000);
+    const uint32_t c_lane = (uint32_t)(s16 * F + f0 + q4 * 16);
+
+    s16x4_t dzf[ST], dzn[ST];
+    fetch_r(row0(0), 0);
+    load_dz(row0(0), dzf);
+    for (int ti = 0; ti < ntile; ++ti) {
+        const int buf = ti & 1;
+        const int64_t m0 = row0(ti);
+        // this tile's R sub-tile has landed (own DMA only).  PASS 1: the previous tile's ST stores are younger and stay in flight
+        if (PASS == 1 && ti > 0) wait_vmcnt<ST>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ti + 1 < ntile) { fetch_r(row0(ti + 1), buf ^ 1); load_dz(row0(ti + 1), dzn); }
+        f32x4_t acc[4][ST];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int st = 0; st < ST; ++st)
+                acc[ft][st] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wfrag[ft], dzf[st], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const unsigned char* Rw = smem + (wave * 2 + buf) * R_BYTES;
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+            const int row = st * 16 + s16;
+            const bool live = m0 + row < a.M;
+            const int rsw = (row >> 2) & 3;
+            uint32_t d[4];
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                float rv[4];
+                f8_unpack4(*(const uint32_t*)(Rw + row * 64 + ((ft ^ rsw) << 4) + 4 * q4), rv);
+                float y[4] = {acc[ft][st][0], acc[ft][st][1], acc[ft][st][2], acc[ft][st][3]};
+                if (a.dp_thresh != 0) {
+                    const uint32_t col = (uint32_t)(f0 + ft * 16 + 4 * q4);
+                    const uint32_t m = (uint32_t)(m0 + row);
+                    const uint32_t p0 = dropout_pair(dkey, m, (uint32_t)F, col);
+                    const uint32_t p1 = dropout_pair(dkey, m, (uint32_t)F, col + 2);
+                    y[0] *= dropout_scale(p0, 0, a.dp_thresh, a.dp_inv_keep);
+                    y[1] *= dropout_scale(p0, 1, a.dp_thresh, a.dp_inv_keep);
+                    y[2] *= dropout_scale(p1, 0, a.dp_thresh, a.dp_inv_keep);
+                    y[3] *= dropout_scale(p1, 1, a.dp_thresh, a.dp_inv_keep);
+                }
+                if constexpr (PASS == 1) {
+                    const float4 ca = cfa[ft], cb = cfb[ft], cz = cfz[ft];
+                    y[0] = rv[0] > 0.f ? fmaf(ca.x, y[0], fmaf(cb.x, rv[0], cz.x)) : 0.f;
+                    y[1] = rv[1] > 0.f ? fmaf(ca.y, y[1], fmaf(cb.y, rv[1], cz.y)) : 0.f;
+                    y[2] = rv[2] > 0.f ? fmaf(ca.z, y[2], fmaf(cb.z, rv[2], cz.z)) : 0.f;
+                    y[3] = rv[3] > 0.f ? fmaf(ca.w, y[3], fmaf(cb.w, rv[3], cz.w)) : 0.f;
+                    amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
+                    amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
+                    d[ft] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float w = live ? y[e] : 0.f;
+                    s1[ft * 4 + e] += w;
+                    if constexpr (PASS == 0) s2[ft * 4 + e] = fmaf(w, rv[e], s2[ft * 4 + e]);
+                }
+            }
+            if constexpr (PASS == 1) {
+                { const auto x = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false); d[0] = x[0]; d[2] = x[1]; }
+                { const auto x = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false); d[1] = x[0]; d[3] = x[1]; }
+                { const auto x = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false); d[0] = x[0]; d[1] = x[1]; }
+                { const auto x = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false); d[2] = x[0]; d[3] = x[1]; }
+                const u32x4_t c = {d[0], d[1], d[2], d[3]};
+                store_b128_settled(c, c_rsrc, c_lane, (uint32_t)((m0 + st * 16) * F), 0);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < ST; ++st) dzf[st] = dzn[st];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float u1 = f8_exp2i(-e_o), u2 = f8_exp2i(-e_r);
+    float r1[2], r2[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        float v1[8], v2[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { v1[p] = s1[hh * 8 + p]; v2[p] = PASS == 0 ? s2[hh * 8 + p] : 0.f; }
+        r1[hh] = row16_fold8(v1, lane) * u1;
+        r2[hh] = PASS == 0 ? row16_fold8(v2, lane) * u2 : 0.f;
+    }
+    if (s16 < 8) {
+        const int64_t prow = (int64_t)wkr * 8 + xcd;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int idx = hh * 8 + s16, f = f0 + (idx >> 2) * 16 + 4 * q4 + (idx & 3);
+            if constexpr (PASS == 0) {
+                a.partials[(prow * 2 + 0) * F + f] = r1[hh];
+                a.partials[(prow * 2 + 1) * F + f] = r2[hh];
+            } else {
+                a.partials[prow * F + f] = r1[hh];
+            }
+        }
+    }
+    if constexpr (PASS == 1) f8_atomic_amax(&a.st->amax[a.t_out], amax);
+}
+
+template <int PASS>
+static inline hipError_t launch_proj_dgrad8(const Proj8Args& a, hipStream_t st, int* stat_rows) {
+    if (a.K < 16 || (a.K & 3) || !a.R || (PASS == 1 && !a.coef) || (uint64_t)a.M * 512 >= 0xFFF00000ull) return hipErrorInvalidValue;
+    const int blocks = 1024, nwk = (blocks >> 3) / 2;
+    const int64_t tiles = (a.M + 31) / 32, workers = (int64_t)nwk * 8;
+    if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
+    hipLaunchKernelGGL(proj_dgrad8_kernel<PASS>, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
 }

@@ -10,7 +10,9 @@
 #include "common.cuh"
 
 enum { YLOAD_PLAIN = 0, YLOAD_CONV = 1,
-       YLOAD_BNDROP = 2 };   // Y = dropout(BatchNorm(saved activation)) formed while staging (y_scale/y_shift + the dp_* fields; Q = row width)
+       YLOAD_BNDROP = 2,     // Y = dropout(BatchNorm(saved activation)) formed while staging (y_scale/y_shift + the dp_* fields; Q = row width)
+       YLOAD_F8 = 3,         // Y is stored as e4m3 (ldy in bytes) with the scale 2^*y_exp: converted to T while staging (bf16 kernels only)
+       YLOAD_BNDROP_F8 = 4 };// both
 
 struct GemmTNArgs {
     const void* X;          // [M][ldx] T
@@ -18,6 +20,7 @@ struct GemmTNArgs {
     float* slabs;           // [S][P][Q]
     const float* y_scale;   // YLOAD_CONV: BN affine of the input channels (64) or nullptr
     const float* y_shift;
+    const int* y_exp;       // YLOAD_F8 / YLOAD_BNDROP_F8: device word holding Y's scale exponent
     int64_t M;
     int64_t rows_per_split; // multiple of 32
     int ldx, ldy, P, Q;
@@ -82,6 +85,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     const T* __restrict__ Xg = (const T*)a.X;
     const T* __restrict__ Yg = (const T*)a.Y;
     uint4 xreg[X_IT], yreg[Y_IT];
+    float y_deq = 1.f;
+    if constexpr (YLOAD == YLOAD_F8 || YLOAD == YLOAD_BNDROP_F8) y_deq = f8_exp2i(-*a.y_exp);
 
     auto load_tiles = [&](int step) {
         const int64_t ms = mb + (int64_t)step * 32;
@@ -102,6 +107,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if constexpr (YLOAD == YLOAD_PLAIN) {
                 if (row < 32 && m < me) v = *(const uint4*)(Yg + m * a.ldy + q0 + ch * EPC);
+            } else if constexpr (YLOAD == YLOAD_F8 || YLOAD == YLOAD_BNDROP_F8) {
+                static_assert(sizeof(T) == 2 || (YLOAD != YLOAD_F8 && YLOAD != YLOAD_BNDROP_F8), "e4m3 operands feed the bf16 kernels");
+                if (row < 32 && m < me) {
+                    v = f8_chunk_to_bf16(*(const uint2*)((const uint8_t*)a.Y + m * a.ldy + q0 + ch * 8), y_deq);
+                    if constexpr (YLOAD == YLOAD_BNDROP_F8)
+                        v = bn_drop_chunk<T>(v, a.y_scale, a.y_shift, q0 + ch * EPC, a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key, (uint32_t)m,
+                                             (uint32_t)a.Q, a.dp_thresh, a.dp_inv_keep);
+                }
             } else if constexpr (YLOAD == YLOAD_BNDROP) {
                 if (row < 32 && m < me)
                     v = bn_drop_chunk<T>(*(const uint4*)(Yg + m * a.ldy + q0 + ch * EPC), a.y_scale, a.y_shift, q0 + ch * EPC,

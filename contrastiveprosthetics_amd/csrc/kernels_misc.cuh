@@ -475,7 +475,9 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ partials, in
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int P, int Q, int p_valid,
                                     const float* __restrict__ s, const float* __restrict__ t,
                                     const float* __restrict__ dbsum, float* __restrict__ grad, int mode,
-                                    float* __restrict__ raw) {
+                                    float* __restrict__ raw, const int* __restrict__ exp_x = nullptr, const int* __restrict__ exp_y = nullptr) {
+    // exp_x / exp_y (CP_FP8): scale exponents of the two 8-bit operands of the product; the slabs hold it in stored units
+    const float unscale = exp_x != nullptr ? f8_exp2i(-*exp_x - *exp_y) : 1.f;
     const int64_t total = (int64_t)p_valid * Q;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int p = (int)(i / Q), q = (int)(i % Q);
@@ -491,7 +493,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
             a3 += src[(k + 3) * sstride];
         }
         for (; k < S; ++k) a0 += src[k * sstride];
-        float acc = (a0 + a1) + (a2 + a3);
+        float acc = ((a0 + a1) + (a2 + a3)) * unscale;
         if (raw != nullptr) raw[i] = acc;              // un-fixed product g_y^T r, input of bn_bwd_sums_from_wgrad_kernel
         if (mode == 2) {
             const int tap = q >> 6, ii = q & 63;

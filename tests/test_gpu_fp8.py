@@ -160,3 +160,53 @@ def test_step_runs_and_learns():
           f"max |difference| of the 10-step means {np.abs(a.reshape(-1, 10).mean(1) - b.reshape(-1, 10).mean(1)).max():.4f}")
     assert b[-10:].mean() < b[:5].mean() - 0.3, "the fp8 path does not learn"
     assert abs(b[-10:].mean() - a[-10:].mean()) < 0.05 * a[-10:].mean(), "fp8 and bf16 loss curves part by more than 5 %"
+
+
+@pytest.mark.parametrize("dp", [0.0, 0.0635])
+@pytest.mark.parametrize("B", [64, 5])
+def test_backward_8bit_against_the_bf16_bridge(dp, B, monkeypatch):
+    """the 8-bit backward kernels (e5m2 gradients, e4m3 activations and W^T) against the bf16 backward kernels run on the SAME
+    forward pass's tensors (CPNATIVE_FP8_BRIDGE): every parameter gradient by cosine and by norm.  What separates the two is the
+    rounding of the gradients between layers to two mantissa bits; a wrong lane map, scale or mask gives cosines near zero."""
+    sd = nontrivial_sd(53, False)
+    EMG = randn(505, (B, T, 1, 1, 12))
+    label = torch.arange(T).repeat(B).cuda()
+    x = EMG.reshape(-1, 12).cuda()
+    grads = {}
+    for mode in ("bridge", "native"):
+        if mode == "bridge":
+            monkeypatch.setenv("CPNATIVE_FP8_BRIDGE", "1")
+        else:
+            monkeypatch.delenv("CPNATIVE_FP8_BRIDGE", raising=False)
+        e = make_engine(sd, False, "fp8", dp=dp, seed=11)
+        for _ in range(3):                         # (the third step runs with scales calibrated by the first two, gradients included)
+            e.step_count = 0                       # same dropout masks in every pass and in both modes
+            e.grads.flat.zero_()
+            z = e.encoder_forward(x, training=True)
+            out, pred, _ = e.head(z, label, 1, want_grad=True)
+            e.encoder_backward(x)
+        torch.cuda.synchronize()
+        grads[mode] = {k: v.clone().cpu().double() for k, v in e.grads.views.items()}
+        assert all(bool(torch.isfinite(v).all()) for v in grads[mode].values()), mode
+    worst = (1.0, "")
+    report, bad = [], []
+    for k, gb in grads["bridge"].items():
+        gn = grads["native"][k]
+        if float(gb.norm()) == 0.0:
+            continue
+        cos = float((gb * gn).sum() / (gb.norm() * gn.norm() + 1e-300))
+        ratio = float(gn.norm() / gb.norm())
+        worst = min(worst, (cos, k))
+        report.append(f"  {k:36s} cos {cos:.4f} norm ratio {ratio:.3f}")
+        # Linear biases in front of a BatchNorm: their gradient is the column sum of a gradient whose column mean the BatchNorm
+        # backward has just removed -- what is left is a small difference of large numbers, and two-bit rounding noise of the
+        # summands shows in it (the weight gradients, sums of the same summands against the layer input, do not cancel)
+        is_bias = k.endswith(".bias") and ("linear" in k or "conv_emg.3" in k or "conv_emg.0" in k)
+        lim = 0.90 if "conv_emg" in k else 0.97          # (the conv stack sits behind seven re-quantised gradients)
+        if is_bias:
+            lim = 0.5
+        if not (cos > lim and (is_bias or 0.85 < ratio < 1.15)):
+            bad.append(report[-1])
+    print(f"\n8-bit backward vs bf16 bridge (dp={dp}, B={B}): worst cosine {worst[0]:.4f} at {worst[1]}")
+    print("\n".join(report))
+    assert not bad, "8-bit vs bridged gradients:\n" + "\n".join(bad)
