@@ -38,54 +38,65 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}
 
 
-# profiler kind -> (the ONE kernel it times, as rocprofv3 names it; fc layer indices it runs on when dropout is on / off)
-# ({dyn} = the tile schedule, include/cpnative.h cp_set_tile_schedule: "false" static, "true" dynamic)
+# profiler kind -> the ONE kernel it times, as rocprofv3 names it ({dyn} = the tile schedule, include/cpnative.h
+# cp_set_tile_schedule: "false" static, "true" dynamic).  The library has ONE kernel per kind since round 3 (the superseded
+# variants moved to the tools-only build, csrc/variants.cuh).
 GEMM_KERNELS = {
-    "fc_fwd_ws": "gemm_ws16_kernel",                      # weight-stationary forward, fc2..fc7 (K = 512), static schedule
-    "fc_fwd": "gemm_ws16k_kernel",                        # weight-stationary with the k range split over wave pairs: fc1 (K = 768)
-    "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
-    "fc_dgrad_bn": "gemm_wsd16_kernel<0>",                # weight-stationary, + BN/ReLU backward of the layer below against the saved activation
-    "fc_dgrad_stats": "gemm_wsd16_kernel<1>",             # weight-stationary, behind a dropout: mask + BN-backward sums against the saved activation
-    "fc_wgrad": "gemm_tn256_kernel",
+    "bf16": {
+        "fc_fwd_ws": "gemm_ws16_kernel",                      # weight-stationary forward, fc2..fc7 (K = 512), static schedule
+        "fc_fwd": "gemm_ws16k_kernel",                        # weight-stationary with the k range split over wave pairs: fc1 (K = 768)
+        "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
+        "fc_dgrad_bn": "gemm_wsd16_kernel<0>",                # + BN/ReLU backward of the layer below against the saved activation
+        "fc_dgrad_stats": "gemm_wsd16_kernel<1>",             # behind a dropout: mask + BN-backward sums against the saved activation
+        "fc_wgrad": "gemm_tn256_kernel",
+    },
+    "fp8": {                                                  # csrc/fp8.cuh: block-scaled MFMA, e4m3 activations / weights, e5m2 gradients
+        "fc_fwd_ws": "gemm_ws8_kernel<512>",
+        "fc_fwd": "gemm_ws8_kernel<768>",
+        "fc_dgrad_bn": "gemm_wsd8_kernel<0, false>",
+        "fc_dgrad_conv": "gemm_wsd8_kernel<0, true>",         # fc1's data gradient: 16-bit output for the conv kernels
+        "fc_dgrad_stats": "gemm_wsd8_kernel<1, false>",
+        "fc_wgrad": "gemm_tn8_kernel",
+    },
 }
+GEMM_KERNELS["f32"] = {k: "gemm_nt_kernel / gemm_tn_kernel<float>" for k in GEMM_KERNELS["bf16"]}
 
 
-def gemm_symbol(kind: str, dyn: str) -> str:
-    """The kernel symbol a GEMM kind runs as under this process's switches (csrc/gemm_ws.cuh launchers): the
-    16x16x32 weight-stationary kernels by default, their 32x32x16 forms or the tile-staged kernels on request."""
-    env = os.environ
-    if kind == "fc_fwd_ws" and env.get("CPNATIVE_WS32"):
-        return "gemm_ws_kernel<0, 4>"
-    if kind == "fc_fwd" and (env.get("CPNATIVE_NO_WS") or env.get("CPNATIVE_NO_WSK")):
-        return "gemm_nt256p_kernel<0, 4, %s>" % dyn
-    if kind == "fc_dgrad_bn":
-        if env.get("CPNATIVE_NO_WSD"):
-            return "gemm_nt256p_kernel<3, 4, %s>" % dyn
-        if env.get("CPNATIVE_WS32") or env.get("CPNATIVE_WSD32"):
-            return "gemm_wsd_bn_kernel"
-    if kind == "fc_dgrad_stats" and (env.get("CPNATIVE_NO_WSD") or env.get("CPNATIVE_NO_WSD_ST")):
-        return "gemm_nt256p_kernel<4, 4, %s>" % dyn
-    return GEMM_KERNELS[kind].format(dyn=dyn)
+def gemm_symbol(kind: str, dyn: str, dtype: str = "bf16") -> str:
+    if dtype == "bf16" and (os.environ.get("CPNATIVE_TILE_SCHEDULE") == "dynamic" or dyn == "true"):
+        if kind in ("fc_fwd_ws", "fc_fwd"):
+            return "gemm_nt256p_kernel<0, 4, true>"
+        if kind == "fc_dgrad_bn":
+            return "gemm_nt256p_kernel<3, 4, true>"
+        if kind == "fc_dgrad_stats":
+            return "gemm_nt256p_kernel<4, 4, true>"
+    return GEMM_KERNELS[dtype][kind].format(dyn=dyn)
 
 
-def gemm_model(kind: str, n: int, es: int, dropout: bool):
+def gemm_model(kind: str, n: int, dtype: str, dropout: bool):
     """Algorithmic (bytes, flops) of ONE average launch of a GEMM kind over n windows (DESIGN.md
     'measurement'): fc layers are 768->512 then 6 x 512->512; every activation/gradient element is
-    moved once per kernel that must touch it (BN-barrier model).  Dropout sits on the inputs
-    of fc5..fc7: their data-gradient launches (kind fc_dgrad_stats) also read the saved activation; the
-    others (kind fc_dgrad) get the BN-backward sums from the weight gradient and read no N-sized tensor for them."""
+    moved once per kernel that must touch it (BN-barrier model), at the element size of the dtype
+    (fp8: 1 byte; fc1's data gradient writes 2-byte elements for the conv kernels).  Dropout sits on the inputs
+    of fc5..fc7: their data-gradient launches (kind fc_dgrad_stats) also read the saved activation (fp8: the dropout
+    output); the others apply BatchNorm + ReLU backward of the layer below against its saved activation."""
     ks = [768] + [512] * 6
-    ws = es == 2 and not os.environ.get("CPNATIVE_NO_WS") and os.environ.get("CPNATIVE_TILE_SCHEDULE") != "dynamic"
+    es = {"f32": 4, "bf16": 2, "fp8": 1}[dtype]
+    ws = dtype != "f32" and os.environ.get("CPNATIVE_TILE_SCHEDULE") != "dynamic"
+    out_es = lambda i: es
     if kind == "fc_fwd_ws":         # read input, write post-ReLU output: the K = 512 layers on the weight-stationary kernel
         layers, per = (range(1, 7) if ws else range(0)), lambda k: k + 512
-    elif kind == "fc_fwd":          # the same on the tile-staged persistent kernel: fc1 (K = 768), or every layer without the ws kernel
+    elif kind == "fc_fwd":          # fc1 (K = 768) on its own kernel, or every layer without the weight-stationary kernels
         layers, per = (range(0, 1) if ws else range(7)), lambda k: k + 512
     elif kind == "fc_dgrad":        # read g_y, write g_v (only with CPNATIVE_UNFUSED_BN_BWD: the plain persistent launch)
-        unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD"))
+        unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD")) and dtype != "fp8"
         layers, per = ((range(4) if dropout else range(7)) if unfused else range(0)), lambda k: 512 + k
     elif kind == "fc_dgrad_bn":     # read g_y and the saved activation of the layer below, write its dL/d(pre-activation)
-        unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD"))
-        layers, per = (range(0) if unfused else (range(4) if dropout else range(7))), lambda k: 512 + 2 * k
+        unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD")) and dtype != "fp8"
+        lo = 1 if dtype == "fp8" else 0                       # (fp8: fc1's launch is its own kind)
+        layers, per = (range(0) if unfused else (range(lo, 4) if dropout else range(lo, 7))), lambda k: 512 + 2 * k
+    elif kind == "fc_dgrad_conv":   # fp8, fc1: read g_y (1 B) and conv2's saved output (1 B), write 2-byte gradients
+        layers, per = (range(0, 1) if dtype == "fp8" else range(0)), lambda k: 512 + k + 2 * k
     elif kind == "fc_dgrad_stats":  # behind a dropout: read g_y and the saved activation, write g_v
         layers, per = (range(4, 7) if dropout else range(0)), lambda k: 512 + 2 * k
     else:                           # fc_wgrad: read g_y and the layer input
@@ -94,11 +105,33 @@ def gemm_model(kind: str, n: int, es: int, dropout: bool):
     if not layers:
         return 0.0, 0.0
     launches = len(layers)
-    if kind == "fc_wgrad" and dropout and es == 2 and not os.environ.get("CPNATIVE_UNPAIRED_WGRAD"):
-        launches -= 2               # bf16 behind a dropout: fc7+fc6 and fc5+fc4 share one launch each (api.hip, defer_wgrad)
+    if kind == "fc_wgrad" and dropout and dtype != "f32" and not os.environ.get("CPNATIVE_UNPAIRED_WGRAD"):
+        launches -= 2               # behind a dropout: fc7+fc6 and fc5+fc4 share one launch each (api.hip, defer_wgrad)
     byts = sum(n * es * per(ks[i]) for i in layers) / launches
     flops = sum(2.0 * n * 512 * ks[i] for i in layers) / launches
     return byts, flops
+
+
+def measure_practical_peaks(dev, dtype):
+    """What this box sustains, measured here in ~30 ms: HBM by a 1 GiB device-to-device copy (read + write bytes / time), the
+    matrix pipe from the committed probe outputs (profiles/): a live MFMA loop would need its own kernel in the library."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    gbs = 5 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    mfma = {"bf16": dict(tflops=1200.0, source="DESIGN.md section 4 / profiles/r02_probes.txt: MFMA + LDS-read loop on random bf16 data, chip at its power cap"),
+            "fp8": dict(tflops=3300.0, source="profiles/r03_fp8_probe.txt: v_mfma_scale_f32_16x16x128_f8f6f4 loop on random e4m3 data"),
+            "f32": dict(tflops=155.0, source="MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 measured")}[dtype]
+    return dict(hbm_gbs=gbs, hbm_source="1 GiB torch device copy timed in this run (read + write)", mfma_tflops=mfma["tflops"], mfma_source=mfma["source"])
 
 
 def cpu_baseline(seconds: float, threads: int):
@@ -255,7 +288,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    gemm_kinds = ["fc_fwd_ws", "fc_fwd", "fc_dgrad", "fc_dgrad_bn", "fc_dgrad_stats", "fc_wgrad"]
+    gemm_kinds = ["fc_fwd_ws", "fc_fwd", "fc_dgrad", "fc_dgrad_bn", "fc_dgrad_conv", "fc_dgrad_stats", "fc_wgrad"]
     eng.profile_enable(gemm_kinds, max_records=64 * (args.steps + 1))
     # one event per step boundary on the launch stream: min / median / max step time inside the timed region (the same
     # launch moves by +-10 % with the clock state of the box; the spread says how steady this run was)
@@ -296,47 +329,61 @@ def main():
         print(f"  sum            {tot / 2:8.3f} ms/step", file=sys.stderr)
 
     if rank == 0:
-        es = 4 if args.dtype == "f32" else 2
+        dt = args.dtype
+        prefix = {"bf16": "r03", "fp8": "r03_fp8", "f32": "r03_f32"}[dt]
         dom = max(gemm_kinds, key=lambda k: prof.get(k, (0.0, 0))[0])
         ms, launches = prof[dom]
-        mfma_busy = None                 # counter evidence, from the committed SQ pass of this same command (tools/profile_round.sh)
-        mpath = os.path.join(ROOT, "profiles", "r02_mfma.json")
-        if args.dtype == "bf16" and B == 4096 and os.path.exists(mpath):
-            for k, v in json.load(open(mpath))["kernels"].items():
-                if gemm_symbol(dom, "true" if eng.lib.cp_get_tile_schedule() else "false") in k:
-                    mfma_busy = v["mfma_busy_frac"]
-        avg_s = ms / launches / 1e3
-        byts, flops = gemm_model(dom, N, es, args.dp_emg > 0)
-        gbs = byts / avg_s / 1e9
-        tfl = flops / avg_s / 1e12
-        mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
-        # HBM bytes per launch from the committed PMC profile of this same command (tools/parse_profile.py,
-        # separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction); null if not profiled
-        traffic = None
         dyn = "true" if eng.lib.cp_get_tile_schedule() else "false"
-        kname = gemm_symbol(dom, dyn)
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if args.dtype == "bf16" and B == 4096 and os.path.exists(tpath):
+        kname = gemm_symbol(dom, dyn, dt)
+        # counter evidence from the COMMITTED profiles of this same command on the builder's box (tools/profile_round.sh): not
+        # measured in this run, and labelled so
+        mfma_busy = traffic = None
+        mpath = os.path.join(ROOT, "profiles", prefix + "_mfma.json")
+        tpath = os.path.join(ROOT, "profiles", prefix + "_traffic.json")
+        if B == 4096 and os.path.exists(mpath):
+            for k, v in json.load(open(mpath))["kernels"].items():
+                if kname in k:
+                    mfma_busy = dict(value=v["mfma_busy_frac"], source="profiles/" + os.path.basename(mpath) + " (SQ counters, builder's box)")
+        if B == 4096 and os.path.exists(tpath):
             for k, v in json.load(open(tpath))["kernels"].items():
                 if kname in k:
-                    traffic = v["hbm_bytes_per_launch"]
+                    traffic = dict(value=v["hbm_bytes_per_launch"], source="profiles/" + os.path.basename(tpath) + " (PMC FETCH_SIZE / WRITE_SIZE passes, builder's box)")
+        avg_s = ms / launches / 1e3
+        byts, flops = gemm_model(dom, N, dt, args.dp_emg > 0)
+        gbs = byts / avg_s / 1e9
+        tfl = flops / avg_s / 1e12
+        mfma_peak = MFMA_PEAK_TFLOPS[dt]
+        practical = measure_practical_peaks(dev, dt)
         per_kernel = {}
         for k in gemm_kinds:
             if k in prof and prof[k][1] > 0:
-                kb, kf = gemm_model(k, N, es, args.dp_emg > 0)
+                kb, kf = gemm_model(k, N, dt, args.dp_emg > 0)
                 ks_ = prof[k][0] / prof[k][1] / 1e3
-                per_kernel[k] = dict(symbol=gemm_symbol(k, dyn), launches=prof[k][1], avg_us=ks_ * 1e6, algorithmic_bytes=kb,
+                per_kernel[k] = dict(symbol=gemm_symbol(k, dyn, dt), launches=prof[k][1], avg_us=ks_ * 1e6, algorithmic_bytes=kb,
                                      gbs=kb / ks_ / 1e9, hbm_frac=kb / ks_ / 1e9 / HBM_PEAK_GBS, tflops=kf / ks_ / 1e12)
         bound = "hbm" if byts / (HBM_PEAK_GBS * 1e9) >= flops / (mfma_peak * 1e12) else "mfma"
+        # the same question against what the chip sustains: a launch whose FLOP/byte lies above practical MFMA / practical HBM is
+        # bounded by the matrix pipe's power budget, and its HBM fraction cannot reach 1
+        bound_practical = "hbm" if byts / (practical["hbm_gbs"] * 1e9) >= flops / (practical["mfma_tflops"] * 1e12) else "mfma"
+        frac_practical = max(gbs / practical["hbm_gbs"], tfl / practical["mfma_tflops"])
         roof = dict(bound=bound, kernel=dom, kernel_symbol=kname, launches=launches, avg_us=avg_s * 1e6,
                     achieved=gbs if bound == "hbm" else tfl, peak=HBM_PEAK_GBS if bound == "hbm" else mfma_peak,
                     unit="GB/s" if bound == "hbm" else "TFLOP/s",
-                    frac=(gbs / HBM_PEAK_GBS) if bound == "hbm" else (tfl / mfma_peak), traffic=traffic,
+                    frac=(gbs / HBM_PEAK_GBS) if bound == "hbm" else (tfl / mfma_peak),
+                    traffic=traffic["value"] if traffic else None, traffic_source=traffic["source"] if traffic else None,
                     algorithmic_bytes=byts,
-                    mfma_tflops=tfl, mfma_frac=tfl / mfma_peak, mfma_busy_frac=mfma_busy, hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
+                    practical_peak=practical, bound_practical=bound_practical, frac_practical=frac_practical,
+                    mfma_tflops=tfl, mfma_frac=tfl / mfma_peak,
+                    mfma_busy_frac=mfma_busy["value"] if mfma_busy else None, mfma_busy_source=mfma_busy["source"] if mfma_busy else None,
+                    hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
                     gemm_ms_per_step={k: prof[k][0] / profiled_steps for k in gemm_kinds if k in prof},
                     profiled_steps=profiled_steps,
                     per_kernel=per_kernel)
+        # the step as a whole against SURVEY 8d's byte model (51.3 KB per window in 16-bit storage, 102.5 in f32, 25.6 in 8-bit)
+        kb_per_window = {"bf16": 51.3, "f32": 102.5, "fp8": 25.6}[dt]
+        step_s = elapsed / args.steps
+        roof["step"] = dict(model_kb_per_window=kb_per_window, hbm_frac=kb_per_window * 1e3 * N / step_s / (HBM_PEAK_GBS * 1e9),
+                            mfma_frac=12.74e6 * N / step_s / (mfma_peak * 1e12))
         rec = dict(metric="sEMG windows/sec contrastive step, 12-ch Ninapro, 1/2/4/8 MI355X", value=world * N * args.steps / elapsed,
                    unit="windows/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,

@@ -107,7 +107,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_
 
 KERNEL_KINDS = ["gather", "prep", "conv1_fwd", "bn_finalize", "conv2_fwd", "fold", "fc_fwd", "dropout", "proj_fwd",
                 "head", "proj_bwd", "bn_bwd", "fc_wgrad", "reduce_slabs", "fc_dgrad", "conv2_wgrad", "conv2_dgrad",
-                "conv1_bwd", "optimizer", "fc_dgrad_stats", "fc_dgrad_bn", "fc_fwd_ws"]
+                "conv1_bwd", "optimizer", "fc_dgrad_stats", "fc_dgrad_bn", "fc_fwd_ws", "fc_dgrad_conv"]
 
 _lib = None
 

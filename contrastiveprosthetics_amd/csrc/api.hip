@@ -1447,7 +1447,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         Transpose8Batch tb{};
         for (int i = 0; i < CP_N_FC; ++i)
             tb.job[i] = Transpose8Job{p->fc_w[i], base + w.wfc8t[i], base + w.wsc8t[i], fcK(i), i == 0 ? 1 : 0, F8_T_GRAD + (i + 2)};
-        hipLaunchKernelGGL(transpose_w8_batch_kernel, dim3(12, CP_N_FC), dim3(256), 0, st, tb, (const Fp8State*)fs);
+        hipLaunchKernelGGL(transpose_w8_batch_kernel, dim3(12, CP_N_FC, 4), dim3(256), 0, st, tb, (const Fp8State*)fs);
         hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(64), dim3(256), 0, st, p->last_w, (T*)(base + w.wlast_t), CP_D_E, 512, 64, 0);
         CKL("transpose kernels (fp8)");
     }
@@ -1584,7 +1584,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             a.coef = coef; a.coef_mod = Cp;
             int drows = 0;
             {
-                ProfScope ps(CP_K_FC_DGRAD_BN, st);
+                ProfScope ps(Lp == 1 ? CP_K_FC_DGRAD_CONV : CP_K_FC_DGRAD_BN, st);
                 if (Lp == 1) { a.C = gconv; a.t_out = -1; CK((launch_gemm_wsd8<0, true>(a, st, &drows))); }
                 else { a.C = nxt; a.t_out = F8_T_GRAD + Lp; CK((launch_gemm_wsd8<0, false>(a, st, &drows))); }
             }
@@ -1598,8 +1598,9 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             }
             bn_done = true;
         } else {
+            // (the dropout OUTPUT of layer Lp stands in for its saved activation: its zeros are the mask -- fp8.cuh, MODE 1)
             a.C = nxt; a.t_out = F8_T_GB + Lp;
-            a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c);
+            a.R = base + w.u8[Lp - 5]; a.t_r = F8_T_U + (Lp - 5); a.bn_stats = stats(Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg);
             ProfScope ps(CP_K_FC_DGRAD_STATS, st);
             int drows = 0;
             CK((launch_gemm_wsd8<1, false>(a, st, &drows)));

@@ -112,17 +112,28 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-// element (row, col) of an [rows x ld] tensor; ld even, col even -> draws for col, col+1.
-// The pair index goes through the two multiply-xorshift rounds of hash32 with the key folded in before the first and
-// (rotated by 16) before the second: two v_mul_lo_u32 per pair instead of three (the 32-bit multiply issues at quarter
-// rate, and the data-gradient epilogue behind a dropout makes 64 of these draws per wave and tile).  Checked on 4M
-// consecutive indices: drop rate 0.06350 for threshold 0.0635, lag-1 / half-to-half / key-to-key mask correlations
-// (keys one bit apart, in either half) all below 0.002.  (Measured: the dropout data-gradient launches did not get
-// faster by it, 178 us either way -- the multiplies were not what bounds that epilogue.)
+// Four 16-bit draws for elements (row, col .. col+3) of an [rows x ld] tensor (ld, col multiples of 4) from ONE hash chain on the
+// full-rate 24-bit multiply (v_mul_u32_u24): fold, multiply, key, fold, then two multiplies of the same word by different
+// constants give 2 x 32 bits.  Round 3: the first form (two 32-bit multiplies per PAIR -- v_mul_lo_u32 issues at quarter rate)
+// made the 8-bit dropout pass and the data-gradient epilogue behind a dropout VALU-bound (SQ_ACTIVE_INST_VALU 2.4x the matrix
+// pipe's busy cycles); this one is 13 full-rate instructions per four elements.  Checked in numpy on 4M consecutive indices
+// (tools/dropout_hash_check.py): drop rates 0.0633-0.0635 for p = 0.0635 in all four draws (and 0.00988..0.50013 for p = 0.01..0.5),
+// cross-draw, lag-1, lag-128 (next row) and key-bit-flip mask correlations all below 0.0025.
+__device__ __forceinline__ uint2 dropout_quad(uint32_t key, uint32_t row, uint32_t ld, uint32_t col) {
+    uint32_t x = ((__umul24(row, ld) + col) >> 2) ^ key;        // (rows and ld below 2^24)
+    x ^= x >> 15;
+    x = __umul24(x, 0xB5297Bu);
+    x ^= (key >> 16) | (key << 16);
+    x ^= x >> 13;
+    uint32_t a = __umul24(x, 0x8DA6B5u), b = __umul24(x, 0x3C6EF3u);
+    a ^= a >> 16;
+    b ^= b >> 16;
+    return make_uint2(a, b);
+}
+// draws for col, col+1 (col even): the half of the quad that holds them
 __device__ __forceinline__ uint32_t dropout_pair(uint32_t key, uint32_t row, uint32_t ld, uint32_t col) {
-    uint32_t x = ((row * ld + col) >> 1) ^ key;
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= (key >> 16) | (key << 16); x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
+    const uint2 q = dropout_quad(key, row, ld, col & ~3u);
+    return (col & 2u) ? q.y : q.x;
 }
 __device__ __forceinline__ float dropout_scale(uint32_t pair, int odd, uint32_t thresh, float inv_keep) {
     uint32_t d = odd ? (pair >> 16) : (pair & 0xFFFFu);

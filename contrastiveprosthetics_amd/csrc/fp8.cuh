@@ -199,10 +199,24 @@ template <int K> struct Ws8Cfg;
 template <> struct Ws8Cfg<512> { static constexpr int RT = 64, NBUF = 3; };
 template <> struct Ws8Cfg<768> { static constexpr int RT = 32, NBUF = 4; };
 
+#ifndef WS8_WOVEN
+#define WS8_WOVEN 1
+#endif
 template <int K>
 __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
     constexpr int KB = K / 128, RT = Ws8Cfg<K>::RT, ST = RT / 16, NBUF = Ws8Cfg<K>::NBUF, AHEAD = NBUF - 1;
     constexpr int TILE_BYTES = RT * K, UPW = TILE_BYTES / 1024 / 4, CPR = K / 16;
+    // WOVEN: the previous tile's epilogue (ST parts) rides in the last ST k blocks of the k loop instead of behind it.  The bf16
+    // kernels measured that slower (a busy bf16 matrix pipe leaves the chip no power for vector work beside it); the 8-bit pipe
+    // runs at a quarter of the energy per product, the k loop is 2,048 cycles of MFMAs against ~2,000 of epilogue (SQ counters,
+    // profiles/r03_fp8_sq1.json: VALU active 45k cycles per wave, matrix pipe busy 42k), and an MFMA occupies the issue port for 8
+    // of its 32 cycles.
+    constexpr bool WOVEN = WS8_WOVEN != 0;
+    constexpr int EPI_KB0 = KB - ST;                           // first k block with an epilogue part
+    constexpr int KB_LF = (UPW - 1) / ST;                      // k block of the last fetch unit
+    // stores of one epilogue that are issued AFTER the step's last fetch unit
+    constexpr int SA = WOVEN ? (KB - (KB_LF > EPI_KB0 ? KB_LF : EPI_KB0) < ST ? KB - (KB_LF > EPI_KB0 ? KB_LF : EPI_KB0) : ST) : ST;
+    static_assert(EPI_KB0 >= 0, "one epilogue part per k block");
     constexpr bool PF2 = ST < 4;         // few sample tiles: fragments of k block kb + 1 are requested in front of the MFMAs of kb (two sets)
     static_assert(UPW <= KB * ST, "one fetch unit per (k block, sample tile) slot at most");
     static_assert((AHEAD - 1) * UPW + AHEAD * ST <= 63, "vmcnt range");
@@ -337,8 +351,10 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
                 acc[3][st] = mx_mfma<3>(wreg[3][kb], x, acc[3][st], wscale);
                 if (!PF2 && kb + 1 < KB) fa[0][st] = load_frag(At, kb + 1, st);
             }
+            if constexpr (WITH_EPI && WOVEN)
+                if (kb >= EPI_KB0) epi_st(old, kb - EPI_KB0, (uint32_t)(m_old * a.F), true);
         }
-        if constexpr (WITH_EPI) {
+        if constexpr (WITH_EPI && !WOVEN) {
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t s_old = (uint32_t)(m_old * a.F);
 #pragma unroll
@@ -346,12 +362,12 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // tile ti + 1 must have landed.  vmcnt retires in issue order (tools/vmcnt_order_probe.hip); younger than its fetches are the
-        // fetches of tiles ti + 2 .. ti + AHEAD and the stores of the epilogues that ran since: min(AHEAD, ti) of them
+        // fetches of tiles ti + 2 .. ti + AHEAD and the stores of the epilogues that ran since: min(AHEAD, ti) epilogues, of the
+        // oldest of which only the SA stores behind that step's last fetch count when all AHEAD are there
         const int ne = ti < AHEAD ? ti : AHEAD;
         if (ne == 0) wait_vmcnt<(AHEAD - 1) * UPW>();
-        else if (ne == 1) wait_vmcnt<(AHEAD - 1) * UPW + ST>();
-        else if (ne == 2 || AHEAD == 2) wait_vmcnt<(AHEAD - 1) * UPW + 2 * ST>();
-        else wait_vmcnt<(AHEAD - 1) * UPW + (AHEAD >= 3 ? 3 : 2) * ST>();
+        else if (ne < AHEAD) { if (ne == 1) wait_vmcnt<(AHEAD - 1) * UPW + ST>(); else wait_vmcnt<(AHEAD - 1) * UPW + 2 * ST>(); }
+        else wait_vmcnt<(AHEAD - 1) * UPW + (AHEAD - 1) * ST + SA>();
         __builtin_amdgcn_s_barrier();
     };
     auto drain = [&](f32x4_t (&old)[4][ST], int64_t m_old) {
@@ -521,6 +537,9 @@ __device__ __forceinline__ void f8_unpack4_e5m2(uint32_t w, float* o) {
 struct Transpose8Job { const float* W; uint8_t* out_w; uint8_t* out_sc; int K, mode, t_grad; };
 struct Transpose8Batch { Transpose8Job job[CP_N_FC]; };
 __global__ __launch_bounds__(256) void transpose_w8_batch_kernel(Transpose8Batch b, const Fp8State* __restrict__ st) {
+    // grid (K / 64 column blocks, jobs, 4 quarters of the 512 rows of W): every block finds the column maxima itself (the whole
+    // slice, L2-resident after the first reader) and quantises its quarter.  (The first version -- 84 blocks walking 128 + 128
+    // dependent-latency loads each -- took 49 us.)
     __shared__ float cmax[4][64];
     __shared__ uint8_t tile[64][64 + 4];
     const Transpose8Job j = b.job[blockIdx.y];
@@ -530,23 +549,31 @@ __global__ __launch_bounds__(256) void transpose_w8_batch_kernel(Transpose8Batch
     const int kp = k0 + lane;                                          // row of W^T in the internal order
     const int k = j.mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;       // column of W
     float am = 0.f;
-    for (int jj = grp; jj < 512; jj += 4) am = fmaxf(am, fabsf(j.W[(int64_t)jj * j.K + k]));
+    for (int jj = grp; jj < 512; jj += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = j.W[(int64_t)(jj + 4 * u) * j.K + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) am = fmaxf(am, fabsf(v[u]));
+    }
     cmax[grp][lane] = am;
     __syncthreads();
     am = fmaxf(fmaxf(cmax[0][lane], cmax[1][lane]), fmaxf(cmax[2][lane], cmax[3][lane]));
     const int ek = f8_fit_exp(am, F8_E4M3_MAX);
     const float sc = f8_exp2i(ek);
-    if (grp == 0) {
+    if (grp == 0 && blockIdx.z == 0) {
         int sb = 127 - ek - st->e[j.t_grad];
         j.out_sc[kp] = (uint8_t)(sb < 1 ? 1 : (sb > 254 ? 254 : sb));
     }
-    for (int j0 = 0; j0 < 512; j0 += 64) {
+    for (int j0 = blockIdx.z * 128; j0 < blockIdx.z * 128 + 128; j0 += 64) {
         __syncthreads();
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = j.W[(int64_t)(j0 + grp + 4 * r) * j.K + k];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int jj = grp + 4 * r;
-            const int p = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(j.W[(int64_t)(j0 + jj) * j.K + k] * sc), 0.f, 0, false);
-            tile[lane][jj] = (uint8_t)(p & 255);                       // [k row][j]
+            const int p = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[r] * sc), 0.f, 0, false);
+            tile[lane][grp + 4 * r] = (uint8_t)(p & 255);              // [k row][j]
         }
         __syncthreads();
 #pragma unroll
@@ -564,8 +591,11 @@ __global__ __launch_bounds__(256) void transpose_w8_batch_kernel(Transpose8Batch
 // the accumulator layout, in that tile's epilogue one k loop later (its own vmcnt is the only ordering).
 //   MODE 0: BatchNorm + ReLU backward of the layer below in the epilogue (coef), output = dL/d(its pre-activation), column sums =
 //           its bias gradient.  OUT_BF16: output stored as bf16 in true units (fc1's launch: the conv kernels read 16-bit gradients).
-//   MODE 1: behind a dropout: the forward pass's mask, output = masked dL/d(BatchNorm output) (F8_T_GB), the two BatchNorm-backward
-//           sums against R.
+//   MODE 1: behind a dropout: R is the forward pass's dropout OUTPUT u = mask (s r + t) / (1 - p) (e4m3, stored for the weight
+//           gradient anyway): u != 0 IS the mask (no hash in the epilogue -- the first build recomputed it and spent 2.4x the matrix
+//           pipe's cycles in VALU), output = masked dL/d(BatchNorm output) (F8_T_GB), and the two BatchNorm-backward sums follow
+//           from sum g and sum g u per feature:  sum g r = ((1 - p) sum g u - t sum g) / s   (exact where the mask is 1, and g is 0
+//           elsewhere).  A kept value that rounded to zero in the forward pass (|u| < 2^-10 / scale) counts as dropped.
 // LDS image of R per wave and buffer: row r at r*64, its four 16-byte chunks XORed with (r >> 2) & 3 (rows r, r+4, r+8, r+12 of a
 // ds_read_b32 share their bank group otherwise).
 // ------------------------------------------------------------------------------------------------------------------------
@@ -573,7 +603,8 @@ struct Wsd8Args {
     const uint8_t* A;       // [M][512] e5m2 gradient
     const uint8_t* W;       // [F][512] e4m3 = W^T of the layer, row-scaled (transpose_w8_batch_kernel)
     const uint8_t* wsc;     // [F]
-    const uint8_t* R;       // [M][F] e4m3 saved activation of the layer below
+    const uint8_t* R;       // [M][F] e4m3: MODE 0 saved activation of the layer below, MODE 1 its dropout output u
+    const float* bn_stats;  // MODE 1: [4][F] mean, invstd, scale s, shift t of the layer below (to turn sum g u into sum g r)
     void* C;                // [M][F] e5m2 (or bf16 with OUT_BF16)
     float* partials;        // MODE 0: [workers][F] column sums (true units);  MODE 1: [workers][2][F]
     const float* coef;      // MODE 0: [3][coef_mod]
@@ -615,9 +646,9 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
     const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
     if (ntile == 0) return;
     const int f0 = fb * 256 + wave * 64;
-    const uint32_t dkey = (STATS && a.dp_thresh != 0) ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
     const int e_r = a.st->e[a.t_r], e_o = OUT_BF16 ? 0 : a.st->e[a.t_out];
     const float so = f8_exp2i(e_o);
+    const float keep_so = a.dp_inv_keep * so;                                // MODE 1: 1 / (1 - p) and the output scale
 
     // MODE 0: BatchNorm-backward coefficients of this lane's 16 features, with the scales folded in: the epilogue's result is the
     // output in STORED units:  y 2^eo = ca 2^eo acc + cb 2^(eo - er) r8 + cz 2^eo
@@ -695,7 +726,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
     const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);
     const uint32_t c_lane = OUT_BF16 ? (uint32_t)(s16 * a.F + f0 + foff) * 2 : (uint32_t)(s16 * a.F + f0 + q4 * 16);
 
-    auto epi_st = [&](f32x4_t (&old)[4][ST], const unsigned char* Rw, int st, uint32_t s_old, bool live, int64_t m_old) {
+    auto epi_st = [&](f32x4_t (&old)[4][ST], const unsigned char* Rw, int st, uint32_t s_old, bool live, int64_t /*m_old*/) {
         const int row = st * 16 + s16;
         const int rsw = (row >> 2) & 3;
         uint32_t d[4];
@@ -712,18 +743,10 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
                 y[2] = rv[2] > 0.f ? fmaf(ca.z, y[2], fmaf(cb.z, rv[2], cz.z)) : 0.f;
                 y[3] = rv[3] > 0.f ? fmaf(ca.w, y[3], fmaf(cb.w, rv[3], cz.w)) : 0.f;
             } else {
-                float k0 = so, k1 = so, k2 = so, k3 = so;
-                if (a.dp_thresh != 0) {
-                    const uint32_t col = (uint32_t)(f0 + ft * 16 + 4 * q4);
-                    const uint32_t m = (uint32_t)(m_old + row);
-                    const uint32_t p0 = dropout_pair(dkey, m, (uint32_t)a.F, col);
-                    const uint32_t p1 = dropout_pair(dkey, m, (uint32_t)a.F, col + 2);
-                    k0 = dropout_scale(p0, 0, a.dp_thresh, a.dp_inv_keep) * so;
-                    k1 = dropout_scale(p0, 1, a.dp_thresh, a.dp_inv_keep) * so;
-                    k2 = dropout_scale(p1, 0, a.dp_thresh, a.dp_inv_keep) * so;
-                    k3 = dropout_scale(p1, 1, a.dp_thresh, a.dp_inv_keep) * so;
-                }
-                y[0] *= k0; y[1] *= k1; y[2] *= k2; y[3] *= k3;
+                y[0] = rv[0] != 0.f ? y[0] * keep_so : 0.f;
+                y[1] = rv[1] != 0.f ? y[1] * keep_so : 0.f;
+                y[2] = rv[2] != 0.f ? y[2] * keep_so : 0.f;
+                y[3] = rv[3] != 0.f ? y[3] * keep_so : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -864,8 +887,11 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
         for (int hh = 0; hh < 2; ++hh) {
             const int idx = hh * 8 + s16, f = f0 + (idx >> 2) * 16 + 4 * q4 + (idx & 3);
             if constexpr (STATS) {
+                // sum g u -> sum g r through the layer's BatchNorm affine: u (1 - p) = s r + t wherever g != 0
+                const float sc = a.bn_stats[2 * a.F + f], sh = a.bn_stats[3 * a.F + f], mean = a.bn_stats[f];
+                const float gr = fabsf(sc) > 1e-30f ? (r2[hh] / a.dp_inv_keep - sh * r1[hh]) / sc : mean * r1[hh];
                 a.partials[(prow * 2 + 0) * a.F + f] = r1[hh];
-                a.partials[(prow * 2 + 1) * a.F + f] = r2[hh];
+                a.partials[(prow * 2 + 1) * a.F + f] = gr;
             } else {
                 a.partials[prow * a.F + f] = r1[hh];
             }

@@ -292,7 +292,8 @@ enum {
     CP_K_FC_DGRAD = 14, CP_K_CONV2_WGRAD = 15, CP_K_CONV2_DGRAD = 16, CP_K_CONV1_BWD = 17,
     CP_K_OPT = 18, CP_K_FC_DGRAD_STATS = 19, CP_K_FC_DGRAD_BN = 20,
     CP_K_FC_FWD_WS = 21,         /* forward fc launches that ran the weight-stationary kernel (K = 512: fc2..fc7) */
-    CP_K_COUNT = 22
+    CP_K_FC_DGRAD_CONV = 22,     /* CP_FP8: fc1's data gradient (16-bit output for the conv kernels) -- its own kernel instantiation */
+    CP_K_COUNT = 23
 };
 int cp_profile_enable(uint64_t kind_mask, int32_t max_records);
 int cp_profile_disable(void);

@@ -117,6 +117,24 @@ def main():
         for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"])[:8]:
             print("%-60s busy frac %s  MFMAs/launch %.3g" % (k[:60], "%.3f" % v["mfma_busy_frac"] if v["mfma_busy_frac"] else "n/a",
                                                               v["mfma_instructions_per_launch"]))
+    elif mode == "counters":
+        # every counter of a --pmc pass, averaged per launch and kernel:  parse_profile.py counters <dir> <out.json> [name filter]
+        d = sys.argv[2]
+        flt = sys.argv[4] if len(sys.argv) > 4 else ""
+        agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+        for name, cname, val in db_of(d).execute("select kernel_name, counter_name, value from counters_collection"):
+            if flt and flt not in name:
+                continue
+            a = agg[name][cname]
+            a[0] += float(val)
+            a[1] += 1
+        out = {k: {c: v[0] / max(v[1], 1) for c, v in cs.items()} | {"launches": max(v[1] for v in cs.values())} for k, cs in agg.items()}
+        json.dump(dict(note="per-launch averages of one rocprofv3 --pmc pass (SQ_* wave/wait counters are in quad-cycles summed over waves, "
+                            "SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs, GRBM_GUI_ACTIVE summed over the 8 XCDs)", kernels=out),
+                  open(sys.argv[3], "w"), indent=1)
+        for k, cs in sorted(out.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0) * kv[1]["launches"])[:14]:
+            print(k[:70])
+            print("    " + "  ".join("%s=%.4g" % (c, v) for c, v in sorted(cs.items())))
     else:
         raise SystemExit(__doc__)
 
