@@ -45,7 +45,7 @@ GEMM_KERNELS = {
     "bf16": {
         "fc_fwd_ws": "gemm_ws16_kernel",                      # weight-stationary forward, fc2..fc7 (K = 512), static schedule
         "fc_fwd": "gemm_ws16k_kernel",                        # weight-stationary with the k range split over wave pairs: fc1 (K = 768)
-        "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only with CPNATIVE_UNFUSED_BN_BWD)
+        "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only under cp_debug_set_option "unfused_bn_bwd")
         "fc_dgrad_bn": "gemm_wsd16_kernel<0>",                # + BN/ReLU backward of the layer below against the saved activation
         "fc_dgrad_stats": "gemm_wsd16_kernel<1>",             # behind a dropout: mask + BN-backward sums against the saved activation
         "fc_wgrad": "gemm_tn256_kernel",
@@ -89,12 +89,10 @@ def gemm_model(kind: str, n: int, dtype: str, dropout: bool):
     elif kind == "fc_fwd":          # fc1 (K = 768) on its own kernel, or every layer without the weight-stationary kernels
         layers, per = (range(0, 1) if ws else range(7)), lambda k: k + 512
     elif kind == "fc_dgrad":        # read g_y, write g_v (only with CPNATIVE_UNFUSED_BN_BWD: the plain persistent launch)
-        unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD")) and dtype != "fp8"
-        layers, per = ((range(4) if dropout else range(7)) if unfused else range(0)), lambda k: 512 + k
+        layers, per = range(0), lambda k: 512 + k          # (only under cp_debug_set_option "unfused_bn_bwd": never in this bench)
     elif kind == "fc_dgrad_bn":     # read g_y and the saved activation of the layer below, write its dL/d(pre-activation)
-        unfused = bool(os.environ.get("CPNATIVE_UNFUSED_BN_BWD")) and dtype != "fp8"
         lo = 1 if dtype == "fp8" else 0                       # (fp8: fc1's launch is its own kind)
-        layers, per = (range(0) if unfused else (range(lo, 4) if dropout else range(lo, 7))), lambda k: 512 + 2 * k
+        layers, per = (range(lo, 4) if dropout else range(lo, 7)), lambda k: 512 + 2 * k
     elif kind == "fc_dgrad_conv":   # fp8, fc1: read g_y (1 B) and conv2's saved output (1 B), write 2-byte gradients
         layers, per = (range(0, 1) if dtype == "fp8" else range(0)), lambda k: 512 + k + 2 * k
     elif kind == "fc_dgrad_stats":  # behind a dropout: read g_y and the saved activation, write g_v
@@ -105,7 +103,7 @@ def gemm_model(kind: str, n: int, dtype: str, dropout: bool):
     if not layers:
         return 0.0, 0.0
     launches = len(layers)
-    if kind == "fc_wgrad" and dropout and dtype != "f32" and not os.environ.get("CPNATIVE_UNPAIRED_WGRAD"):
+    if kind == "fc_wgrad" and dropout and dtype != "f32":
         launches -= 2               # behind a dropout: fc7+fc6 and fc5+fc4 share one launch each (api.hip, defer_wgrad)
     byts = sum(n * es * per(ks[i]) for i in layers) / launches
     flops = sum(2.0 * n * 512 * ks[i] for i in layers) / launches

@@ -57,6 +57,8 @@ class cp_glove_params(C.Structure):
 SYMBOLS = {
     "cp_version": (C.c_int, []),
     "cp_last_error": (C.c_char_p, []),
+    "cp_debug_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
+    "cp_has_variants": (C.c_int, []),
     "cp_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_float]),
     "cp_gather_groups": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, C.c_int32, _fp, _fp]),
     "cp_gather_oob_count": (C.c_int, [_fp, C.c_int32, _fp]),

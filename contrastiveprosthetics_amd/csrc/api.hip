@@ -5,6 +5,7 @@
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
+#include <cctype>
 
 #include "../../include/cpnative.h"
 #include "common.cuh"
@@ -41,6 +42,46 @@ static int fail(int code, const char* what) {
     } while (0)
 
 extern "C" int cp_version(void) { return CP_VERSION; }
+
+// ---------------------------------------------------------------------------------------
+// process-wide switches (common.cuh, CpOptions): set explicitly, never read from the environment on a launch path
+// ---------------------------------------------------------------------------------------
+struct OptName { const char* name; int CpOptions::*field; };
+static const OptName kOptNames[] = {
+    {"unfused_bn_bwd", &CpOptions::unfused_bn_bwd}, {"unpaired_wgrad", &CpOptions::unpaired_wgrad}, {"fp8_bridge", &CpOptions::fp8_bridge},
+#ifdef CP_VARIANTS
+    {"no_ws", &CpOptions::no_ws}, {"no_wsk", &CpOptions::no_wsk}, {"no_wsd", &CpOptions::no_wsd}, {"no_wsd_st", &CpOptions::no_wsd_st},
+    {"staged_r_epilogue", &CpOptions::staged_r_epilogue}, {"ws32", &CpOptions::ws32}, {"wsd32", &CpOptions::wsd32}, {"tn_w4", &CpOptions::tn_w4},
+    {"tn16", &CpOptions::tn16}, {"materialize_u8", &CpOptions::materialize_u8}, {"no_proj_fused", &CpOptions::no_proj_fused},
+#endif
+};
+extern "C" int cp_debug_set_option(const char* name, int32_t value) {
+    if (name)
+        for (const OptName& o : kOptNames)
+            if (!strcmp(name, o.name)) { g_opt.*(o.field) = value; return 0; }
+    return fail(CP_ERR_ARG, "cp_debug_set_option: unknown option (the superseded kernels live in the tools-only build, make -C csrc variants)");
+}
+extern "C" int cp_has_variants(void) {
+#ifdef CP_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+#ifdef CP_VARIANTS
+// tools-only build: $CPNATIVE_<NAME> seeds a switch ONCE, when the library is loaded (tools/ab_env.sh and friends)
+static int seed_options_from_env() {
+    for (const OptName& o : kOptNames) {
+        char env[64] = "CPNATIVE_";
+        size_t n = strlen(env);
+        for (const char* c = o.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper(*c);
+        env[n] = 0;
+        if (getenv(env)) g_opt.*(o.field) = 1;
+    }
+    return 0;
+}
+static const int g_opt_seeded = seed_options_from_env();
+#endif
 extern "C" const char* cp_last_error(void) { return g_err; }
 
 // tile schedule of the persistent fc GEMM kernels (cpnative.h); -1 = not chosen yet: $CPNATIVE_TILE_SCHEDULE or static
@@ -307,27 +348,36 @@ template <typename T, int EPI>
 static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int* stat_rows = nullptr) {
     if (stat_rows) *stat_rows = (int)((a.M + fc_bm<T>() - 1) / fc_bm<T>());
     if constexpr (sizeof(T) == 2) {
-        // (dbg 64 / 128, tools only: force the dynamic / static schedule for this launch)
+#ifdef CP_VARIANTS
+        // tools-only build: dbg bits (cp_debug_gemm) and the options pick superseded kernels -- dbg 64 / 128 force the dynamic /
+        // static schedule, 256 / no_ws the tile-staged kernels, 16 / staged_r_epilogue the one-tile kernel with its LDS-staged epilogue
         const bool dyn = (a.dbg & 64) ? true : (a.dbg & 128) ? false : tile_schedule() == CP_TILES_DYNAMIC;
-        // K = 512 forward launches of a process that has the GPU to itself: the weight-stationary kernel (gemm_ws.cuh).
-        // (dbg 256, tools only: the tile-staged kernel instead; $CPNATIVE_NO_WS does the same for a whole process)
-        if (EPI == EPI_FWD && a.K == WS_K && a.lda == WS_K && a.relu && !dyn && !(a.dbg & (16 | 256)) && !getenv("CPNATIVE_NO_WS"))
-            return launch_gemm_ws<EPI_FWD>(a, st, stat_rows);
-        // fc1 (K = 768), same conditions: the split-k weight-stationary kernel ($CPNATIVE_NO_WSK: the tile-staged kernel)
-        if (EPI == EPI_FWD && a.K == WSK_K && a.lda == WSK_K && a.F == 512 && a.relu && !dyn && !(a.dbg & (16 | 256)) && !getenv("CPNATIVE_NO_WS") &&
-            !getenv("CPNATIVE_NO_WSK"))
-            return launch_gemm_ws16k(a, st, stat_rows);
+        const bool ws_ok = !dyn && !(a.dbg & (16 | 256)) && !g_opt.no_ws;
+        const bool wsk_ok = ws_ok && !g_opt.no_wsk;
+        const bool wsd_ok = ws_ok && !g_opt.no_wsd && (a.coef != nullptr || !g_opt.no_wsd_st);
+        const bool staged = (a.dbg & 16) || g_opt.staged_r_epilogue;
+#else
+        const bool dyn = tile_schedule() == CP_TILES_DYNAMIC;
+        const bool ws_ok = !dyn, wsk_ok = !dyn, wsd_ok = !dyn;
+#endif
+        // a process that has the GPU to itself (static schedule): the weight-stationary kernels (gemm_ws.cuh) -- K = 512 forward,
+        // fc1 (K = 768) on the split-k form, data gradients with BatchNorm + ReLU backward or (behind a dropout) the mask + sums
+        if (EPI == EPI_FWD && a.K == WS_K && a.lda == WS_K && a.relu && ws_ok) return launch_gemm_ws<EPI_FWD>(a, st, stat_rows);
+        if (EPI == EPI_FWD && a.K == WSK_K && a.lda == WSK_K && a.F == 512 && a.relu && wsk_ok) return launch_gemm_ws16k(a, st, stat_rows);
+#ifdef CP_VARIANTS
         if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows, dyn);
-        // BatchNorm + ReLU backward in the data-gradient epilogue, static schedule: the weight-stationary form (gemm_ws.cuh)
-        // (and, behind a dropout, the mask + BatchNorm-backward sums; $CPNATIVE_NO_WSD_ST keeps that one on the tile-staged kernel)
-        if (EPI == EPI_DGRAD && a.R != nullptr && (a.coef != nullptr || !getenv("CPNATIVE_NO_WSD_ST")) && a.K == WS_K && a.lda == WS_K && !dyn &&
-            !(a.dbg & (16 | 256)) && !getenv("CPNATIVE_NO_WS") && !getenv("CPNATIVE_NO_WSD"))
-            return launch_gemm_wsd_bn(a, st, stat_rows);
-        if (EPI == EPI_DGRAD && a.R != nullptr && !(a.dbg & 16) && !getenv("CPNATIVE_STAGED_R_EPILOGUE")) {
-            // the persistent kernel's R epilogues: BN + ReLU backward of the layer below (coef), or dropout + BN-backward sums
+#else
+        if (EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) return launch_gemm_nt256p<EPI>(a, st, stat_rows, dyn);
+#endif
+        if (EPI == EPI_DGRAD && a.R != nullptr && a.K == WS_K && a.lda == WS_K && wsd_ok) return launch_gemm_wsd_bn(a, st, stat_rows);
+#ifdef CP_VARIANTS
+        if (staged) return launch_gemm_nt256<EPI>(a, st);
+#endif
+        // the persistent kernel's R epilogues (dynamic schedule, or K != 512): BN + ReLU backward of the layer below (coef), or
+        // dropout + BN-backward sums
+        if constexpr (EPI == EPI_DGRAD)
             return a.coef ? launch_gemm_nt256p<EPI_DGRAD_BN>(a, st, stat_rows, dyn) : launch_gemm_nt256p<EPI_DGRAD_ST>(a, st, stat_rows, dyn);
-        }
-        return launch_gemm_nt256<EPI>(a, st);
+        return hipErrorInvalidValue;
     } else {
         return launch_gemm_nt<T, 128, 128, ALOAD_PLAIN, EPI>(a, st);
     }
@@ -470,7 +520,11 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         int nrows = 0;
         {
             // (profiler kinds name ONE kernel each: K = 512 bf16 launches under the static schedule run gemm_ws_kernel)
-            const bool ws = sizeof(T) == 2 && K == WS_K && tile_schedule() != CP_TILES_DYNAMIC && !getenv("CPNATIVE_NO_WS");
+#ifdef CP_VARIANTS
+            const bool ws = sizeof(T) == 2 && K == WS_K && tile_schedule() != CP_TILES_DYNAMIC && !g_opt.no_ws;
+#else
+            const bool ws = sizeof(T) == 2 && K == WS_K && tile_schedule() != CP_TILES_DYNAMIC;
+#endif
             ProfScope ps(ws ? CP_K_FC_FWD_WS : CP_K_FC_FWD, st);
             CK((launch_fc_gemm<T, EPI_FWD>(a, st, &nrows)));
         }
@@ -483,8 +537,12 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const float *s = stats(Lp) + 2 * 512, *t = stats(Lp) + 3 * 512;
         // dropout(BN(fc7)) is NOT written out for the projection: its two consumers (this launch and the projection's weight
         // gradient) form it from the saved activation while staging their operand -- both are bound by reading those 172 MB, and
-        // the pass that materialised it moved 344 MB.  ($CPNATIVE_MATERIALIZE_U8: the separate pass, as fc4..fc6 still have.)
-        const bool fused_u8 = drop && !getenv("CPNATIVE_MATERIALIZE_U8");
+        // the pass that materialised it moved 344 MB.  (tools-only build, option materialize_u8: the separate pass, as fc4..fc6 still have.)
+#ifdef CP_VARIANTS
+        const bool fused_u8 = drop && !g_opt.materialize_u8;
+#else
+        const bool fused_u8 = drop;
+#endif
         if (drop && !fused_u8) {
             T* u = (T*)(base + w.u[Lp - 5]);
             ProfScope ps(CP_K_DROPOUT, st);
@@ -1197,7 +1255,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     T* cur = (T*)(base + w.gbuf[0]);
     T* nxt = (T*)(base + w.gbuf[1]);
     bool bn_done = false;           // (see the comment above the fc loop)
-    const bool fuse_ok = sizeof(T) == 2 && !getenv("CPNATIVE_UNFUSED_BN_BWD");
+    const bool fuse_ok = sizeof(T) == 2 && !g_opt.unfused_bn_bwd;
     // ---- projection ------------------------------------------------------------------
     {
         ProfScope ps(CP_K_PROJ_BWD, st);
@@ -1215,7 +1273,12 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         ta.X = dz; ta.ldx = 64; ta.Y = Y; ta.ldy = 512; ta.slabs = slabs; ta.M = N; ta.P = 64; ta.Q = 512;
         int S;
         split_rows(N, 128, &S, &ta.rows_per_split);
-        if (drop && !getenv("CPNATIVE_MATERIALIZE_U8")) {
+#ifdef CP_VARIANTS
+        const bool fused_u8 = drop && !g_opt.materialize_u8;
+#else
+        const bool fused_u8 = drop;
+#endif
+        if (fused_u8) {
             // u8 = dropout(BN(fc7)) was never written (encoder_forward_t): formed from the saved activation while staging
             ta.Y = act(8); ta.y_scale = stats(8) + 2 * 512; ta.y_shift = stats(8) + 3 * 512;
             ta.dp_thresh = dp_thresh(c->dp_emg); ta.dp_key = dp_key(c, 8); ta.dp_inv_keep = dp_inv_keep(c->dp_emg); ta.dp_salt = dp_salt(c);
@@ -1252,7 +1315,11 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[6]);
             CKL("colsum_finalize_kernel(fc7, fused)");
             bn_done = true;
-        } else if (fuse_ok && drop && sizeof(T) == 2 && !getenv("CPNATIVE_NO_PROJ_FUSED")) {
+#ifdef CP_VARIANTS
+        } else if (fuse_ok && drop && sizeof(T) == 2 && !g_opt.no_proj_fused) {
+#else
+        } else if (fuse_ok && drop && sizeof(T) == 2) {
+#endif
             // behind fc7's dropout: the rank-16 product is computed twice (gemm_ws.cuh, proj_dgrad_kernel) -- once for the
             // BatchNorm-backward sums, once more with fc7's BN + ReLU backward applied -- instead of being written out for a
             // separate bn_relu_bwd pass
@@ -1307,7 +1374,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         // next layer's (the gradient buffer they read is the ping-pong partner, untouched until that layer's data
         // gradient): two problems x 4 tiles x 32 splits fill the GPU with half the f32 slabs per layer (134 -> 67 MB
         // written and re-read).
-        const bool defer_wgrad = sizeof(T) == 2 && in_drop && (i == 6 || i == 4) && fcK(i - 1) == 512 && !getenv("CPNATIVE_UNPAIRED_WGRAD");
+        const bool defer_wgrad = sizeof(T) == 2 && in_drop && (i == 6 || i == 4) && fcK(i - 1) == 512 && !g_opt.unpaired_wgrad;
         if (defer_wgrad) {
             pend.X = cur; pend.Y = Y; pend.i = i;
             pending = true;
@@ -1617,7 +1684,7 @@ extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, 
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !grads) return fail(CP_ERR_ARG, "cp_encoder_backward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
-    if (cfg->dtype == CP_FP8 && !getenv("CPNATIVE_FP8_BRIDGE"))
+    if (cfg->dtype == CP_FP8 && !g_opt.fp8_bridge)
         return encoder_backward_fp8(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
     if (cfg->dtype == CP_FP8) {
         // (bridge = the first build's route, kept for A/B runs and as the test's comparison: the e4m3 tensors of the forward pass are
@@ -1773,7 +1840,12 @@ extern "C" int cp_debug_activation(const cp_config* cfg, const cp_params* p, con
         return 0;
     }
     const size_t off = layer < CP_N_BN ? w.act[layer] : w.u[layer - CP_N_BN];
-    if (layer == CP_N_BN + 3 && !getenv("CPNATIVE_MATERIALIZE_U8")) {
+#ifdef CP_VARIANTS
+    const bool u8_stored = g_opt.materialize_u8 != 0;
+#else
+    const bool u8_stored = false;
+#endif
+    if (layer == CP_N_BN + 3 && !u8_stored) {
         // dropout(BN(fc7)) is not stored by the forward pass (its consumers form it while staging): write it now, same key
         const int64_t N = cfg->n_windows;
         const float* st8 = (const float*)(base + w.stats[8]);

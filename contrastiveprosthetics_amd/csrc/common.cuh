@@ -13,6 +13,21 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CP_WAVE 64
 
+// Process-wide switches of the library, set through cp_debug_set_option (include/cpnative.h) -- never read from the environment on
+// a launch path.  The product library knows three: orders of the SAME kernels that tests compare.  A tools-only build with
+// -DCP_VARIANTS (make -C csrc variants -> build/libcpnative_variants.so) also carries the kernels that were measured and
+// superseded, with one switch each; there $CPNATIVE_<NAME> seeds the switch once when the library is loaded (tools/ab_env.sh).
+struct CpOptions {
+    int unfused_bn_bwd = 0;      // BatchNorm + ReLU backward as its own pass behind every data gradient (the f32 path's order)
+    int unpaired_wgrad = 0;      // one weight-gradient launch per layer behind a dropout instead of paired launches
+    int fp8_bridge = 0;          // CP_FP8: expand the saved 8-bit tensors to bf16 and run the bf16 backward kernels
+#ifdef CP_VARIANTS
+    int no_ws = 0, no_wsk = 0, no_wsd = 0, no_wsd_st = 0, staged_r_epilogue = 0, ws32 = 0, wsd32 = 0, tn_w4 = 0, tn16 = 0,
+        materialize_u8 = 0, no_proj_fused = 0;
+#endif
+};
+static CpOptions g_opt;
+
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {                   // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
     return __builtin_bit_cast(bf16_t, (__bf16)f);

@@ -22,7 +22,7 @@
 // stored units and the epilogue is clamp + convert.
 //
 // Reference anchor: the reference only gestures at reduced precision (code/train.py:6,37,56,97: `amp` imported, `autocast`
-// commented out).  Parity of this path is "unpinned by construction": tests report its distance to the f32 oracle and to the
+// commented out).  Parity of this path is "unpinned by construction": tests report its distance to the f32 CPU restatement of the reference and to the
 // bf16 path, and gate on finiteness and on the loss.
 #pragma once
 #include "gemm_ws.cuh"

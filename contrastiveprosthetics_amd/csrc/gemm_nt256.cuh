@@ -32,6 +32,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_unifor
                  : "memory");
 }
 
+#ifdef CP_VARIANTS   // superseded by gemm_nt256p.cuh / gemm_ws.cuh: tools-only build (make -C csrc variants)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNTArgs a) {
     using T = bf16_t;
@@ -374,3 +375,5 @@ static inline hipError_t launch_gemm_nt256(const GemmNTArgs& a, hipStream_t st) 
     hipLaunchKernelGGL((gemm_nt256_kernel<EPI>), dim3((unsigned)blocks), dim3(512), 0, st, a);
     return hipGetLastError();
 }
+
+#endif  // CP_VARIANTS

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTN256Args a) {
     }
 }
 
+#ifdef CP_VARIANTS   // measured and not faster: tools-only build
 // FOUR waves, one per SIMD, each a 128 x 128 piece of the block's 256 x 256 tile (256 accumulator registers): 8 fragments feed 16
 // MFMAs per 16-row k step instead of 6 feeding 8 -- a third less LDS read traffic, which in the 8-wave kernel keeps the LDS port as busy
 // as the matrix pipe (96 KiB of fragment reads + 32 KiB of DMA writes per 32-row step against 1,024 MFMA cycles per SIMD).  A lone wave
@@ -366,6 +367,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256w4_kernel(GemmTN256Args a) {
         }
 }
 
+#endif  // CP_VARIANTS
+
 static inline hipError_t launch_gemm_tn256(const GemmTN256Args& a, hipStream_t st) {
     const int ntiles = (a.P / 256) * (a.Q / 256);
     const int groups = (a.splits + 7) / 8;
@@ -373,8 +376,10 @@ static inline hipError_t launch_gemm_tn256(const GemmTN256Args& a, hipStream_t s
     // ($CPNATIVE_TN16: the 16x16x32 form.  Measured in the step, alternating runs on one box: 137.0 / 150.6 us per launch against
     //  134.5 / 147.2 for the 32x32x16 form -- the shape that gained 18 % in the weight-stationary forward gains nothing here, where
     //  both operands come through ds_read_b64_tr_b16 at 0.75 fragment reads per MFMA-equivalent either way.)
-    if (getenv("CPNATIVE_TN_W4")) hipLaunchKernelGGL(gemm_tn256w4_kernel, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(256), 0, st, a);
-    else if (getenv("CPNATIVE_TN16")) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a);
+#ifdef CP_VARIANTS
+    if (g_opt.tn_w4) { hipLaunchKernelGGL(gemm_tn256w4_kernel, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(256), 0, st, a); return hipGetLastError(); }
+    if (g_opt.tn16) { hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a); return hipGetLastError(); }
+#endif
+    hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3((unsigned)(problems * groups * 8 * ntiles)), dim3(512), 0, st, a);
     return hipGetLastError();
 }

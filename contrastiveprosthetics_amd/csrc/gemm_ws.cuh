@@ -57,6 +57,7 @@ __device__ __forceinline__ void bufl16_lds(const u32x4_t& rsrc, uint32_t voff, u
                  : "memory");
 }
 
+#ifdef CP_VARIANTS   // the 32x32x16 form of the forward kernel: superseded by gemm_ws16_kernel, tools-only build
 template <int FI>
 struct WsAcc {
     f32x16 t[FI][2];         // [32-feature tile i of the wave][sample half jj]
@@ -301,6 +302,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmNTAr
         a.partials[(prow * 2 + 1) * a.F + f] = qs2[0];
     }
 }
+
+#endif  // CP_VARIANTS
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The forward kernel on v_mfma_f32_16x16x32_bf16.  Under the chip's power cap the 16x16x32 shape delivers 1.12-1.15x the
@@ -745,6 +748,7 @@ static inline hipError_t launch_gemm_ws16k(const GemmNTArgs& a, hipStream_t st, 
 #define WSD_TILE_BYTES (WSD_RT * WS_K * 2)
 #define WSD16_RT 32          // 48-row tiles (as in the forward) spill here: the epilogue holds R and the coefficients as well
 
+#ifdef CP_VARIANTS   // the 32x32x16 form: superseded by gemm_wsd16_kernel<0>, tools-only build
 __global__ __launch_bounds__(256, 1) void gemm_wsd_bn_kernel(GemmNTArgs a) {
     constexpr int K = WS_K, KB = K / 16, RPW = WSD_RT / 4;
     constexpr int R_OFF = 2 * WSD_TILE_BYTES, COEF_OFF = R_OFF + 4 * 2 * 4096;
@@ -921,6 +925,8 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd_bn_kernel(GemmNTArgs a) {
         a.partials[prow * a.F + f] = qs1[0];                                 // bias gradient of the layer below: rows of F
     }
 }
+
+#endif  // CP_VARIANTS
 
 // The data-gradient kernel on v_mfma_f32_16x16x32_bf16 (see gemm_ws16_kernel): 32-row tiles = 2 sample tiles of 16, the saved
 // activation read in the 16x16 accumulator layout (lane (q4, s): features ft*16 + 4*q4 .. +3 of row st*16 + s).
@@ -1337,13 +1343,19 @@ static inline hipError_t launch_gemm_wsd_bn(const GemmNTArgs& a, hipStream_t st,
         hipLaunchKernelGGL(gemm_wsd16_kernel<1>, dim3(256), dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    const bool m16 = !(a.dbg & 512) && !getenv("CPNATIVE_WS32") && !getenv("CPNATIVE_WSD32");          // (the 32x32x16 form)
+#ifdef CP_VARIANTS
+    const bool m16 = !(a.dbg & 512) && !g_opt.ws32 && !g_opt.wsd32;          // (else the 32x32x16 form)
+#else
+    const bool m16 = true;
+#endif
     const int nfb = a.F >> 8, nwk = 32 / nfb, rt = m16 ? WSD16_RT : WSD_RT;
     const int64_t tiles = (a.M + rt - 1) / rt;
     const int64_t workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
-    if (m16) hipLaunchKernelGGL(gemm_wsd16_kernel<0>, dim3(256), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(gemm_wsd_bn_kernel, dim3(256), dim3(256), 0, st, a);
+#ifdef CP_VARIANTS
+    if (!m16) { hipLaunchKernelGGL(gemm_wsd_bn_kernel, dim3(256), dim3(256), 0, st, a); return hipGetLastError(); }
+#endif
+    hipLaunchKernelGGL(gemm_wsd16_kernel<0>, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -1352,7 +1364,11 @@ template <int EPI>
 static inline hipError_t launch_gemm_ws(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
     if (a.K != WS_K || (a.F & 255) || a.F > 768 || a.lda != WS_K) return hipErrorInvalidValue;
     const int nfb = a.F >> 8, nwk = 32 / nfb;
-    const bool m16 = EPI == EPI_FWD && !(a.dbg & 512) && !getenv("CPNATIVE_WS32");
+#ifdef CP_VARIANTS
+    const bool m16 = EPI == EPI_FWD && !(a.dbg & 512) && !g_opt.ws32;
+#else
+    const bool m16 = true;
+#endif
     const int rt = m16 ? WS16_RT : WS_RT;
     const int64_t tiles = (a.M + rt - 1) / rt;
     const int64_t workers = (int64_t)nwk * 8;
@@ -1360,8 +1376,10 @@ static inline hipError_t launch_gemm_ws(const GemmNTArgs& a, hipStream_t st, int
 #ifndef WS_WAVES
 #define WS_WAVES 4
 #endif
-    // (dbg 512 / $CPNATIVE_WS32: the v_mfma_f32_32x32x16_bf16 form instead of the 16x16x32 one)
-    if (m16) hipLaunchKernelGGL(gemm_ws16_kernel, dim3(256), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_ws_kernel<EPI, WS_WAVES>), dim3(256), dim3(64 * WS_WAVES), 0, st, a);
+#ifdef CP_VARIANTS
+    // (dbg 512 / option ws32: the v_mfma_f32_32x32x16_bf16 form instead of the 16x16x32 one)
+    if (!m16) { hipLaunchKernelGGL((gemm_ws_kernel<EPI, WS_WAVES>), dim3(256), dim3(64 * WS_WAVES), 0, st, a); return hipGetLastError(); }
+#endif
+    hipLaunchKernelGGL(gemm_ws16_kernel, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }

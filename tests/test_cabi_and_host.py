@@ -165,15 +165,15 @@ def test_lr_closed_forms_equal_the_reference_schedulers(final_epochs):
 
 
 def test_register_stationary_gemm_kernel_has_no_spills():
-    """The weight-stationary GEMM kernels (csrc/gemm_ws.cuh: gemm_ws_kernel, gemm_ws16_kernel, gemm_ws16k_kernel, gemm_wsd_bn_kernel,
-    gemm_wsd16_kernel<0|1>) keep 256 weight registers per wave and run at the edge of the 512-register file.  A spill costs them their
+    """The weight-stationary GEMM kernels (csrc/gemm_ws.cuh: gemm_ws16_kernel, gemm_ws16k_kernel, gemm_wsd16_kernel<0|1>; csrc/fp8.cuh:
+    gemm_ws8_kernel<512|768>, gemm_wsd8_kernel<0|1, .>) keep 128-256 weight registers per wave and run at the edge of the 512-register file.  A spill costs them their
     speed (scratch traffic inside the k loop), and in round 2 every build that spilled also returned wrong values -- that turned out to be
     the store-data hazard that csrc/gemm_ws.cuh::store_b128_settled now closes, not the spills themselves; the guard stays for the speed:
     hipcc's resource remarks are checked at build time."""
-    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh"), "gemm_wsd?(16k?)?(_bn)?_kernel"], capture_output=True, text=True,
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh"), "gemm_wsd?(16k?|8)?_kernel"], capture_output=True, text=True,
                          check=True).stdout
     lines = [l for l in out.splitlines() if "gemm_ws" in l]
-    assert len(lines) >= 6, out
+    assert len(lines) >= 9, out
     for l in lines:
         assert re.search(r"spill\s+0\s+scratch\s+0\b", l), l
 
@@ -183,6 +183,20 @@ def test_no_buffer_store_is_followed_by_a_write_of_its_data_registers():
     VALU write of a buffer_store_dwordx4's data registers directly behind the store when the store's soffset is an SGPR, and the
     store then sends the new values for some lanes.  tools/store_hazard_scan.py reads the device assembly of the whole library: no
     96/128-bit buffer store may have such a write within the next two instructions."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "store_hazard_scan.py")], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert out.stdout.strip().startswith("0 unprotected"), out.stdout[-500:]
+    for extra in ([], ["--variants"]):       # the product library, and the tools-only build whose timings DESIGN.md quotes
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "store_hazard_scan.py")] + extra, capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert out.stdout.strip().startswith("0 unprotected"), out.stdout[-500:]
+
+
+def test_no_getenv_on_a_launch_path():
+    """the library reads the environment in two places only: the tile schedule's default (cached at first use) and, in the tools-only
+    build, the one-time seeding of the variant switches (csrc/api.hip, seed_options_from_env)"""
+    import glob
+    hits = []
+    for f in glob.glob(os.path.join(ROOT, "contrastiveprosthetics_amd", "csrc", "*")):
+        for i, line in enumerate(open(f, errors="replace")):
+            if "getenv(" in line and not line.lstrip().startswith("//"):
+                hits.append((os.path.basename(f), i + 1, line.strip()))
+    assert len(hits) == 2 and all(h[0] == "api.hip" for h in hits), hits
+    assert any("CPNATIVE_TILE_SCHEDULE" in h[2] for h in hits) and any("getenv(env)" in h[2] for h in hits), hits

@@ -164,9 +164,9 @@ def test_step_runs_and_learns():
 
 @pytest.mark.parametrize("dp", [0.0, 0.0635])
 @pytest.mark.parametrize("B", [64, 5])
-def test_backward_8bit_against_the_bf16_bridge(dp, B, monkeypatch):
+def test_backward_8bit_against_the_bf16_bridge(dp, B):
     """the 8-bit backward kernels (e5m2 gradients, e4m3 activations and W^T) against the bf16 backward kernels run on the SAME
-    forward pass's tensors (CPNATIVE_FP8_BRIDGE): every parameter gradient by cosine and by norm.  What separates the two is the
+    forward pass's tensors (cp_debug_set_option "fp8_bridge"): every parameter gradient by cosine and by norm.  What separates the two is the
     rounding of the gradients between layers to two mantissa bits; a wrong lane map, scale or mask gives cosines near zero."""
     sd = nontrivial_sd(53, False)
     EMG = randn(505, (B, T, 1, 1, 12))
@@ -174,18 +174,18 @@ def test_backward_8bit_against_the_bf16_bridge(dp, B, monkeypatch):
     x = EMG.reshape(-1, 12).cuda()
     grads = {}
     for mode in ("bridge", "native"):
-        if mode == "bridge":
-            monkeypatch.setenv("CPNATIVE_FP8_BRIDGE", "1")
-        else:
-            monkeypatch.delenv("CPNATIVE_FP8_BRIDGE", raising=False)
         e = make_engine(sd, False, "fp8", dp=dp, seed=11)
-        for _ in range(3):                         # (the third step runs with scales calibrated by the first two, gradients included)
-            e.step_count = 0                       # same dropout masks in every pass and in both modes
-            e.grads.flat.zero_()
-            z = e.encoder_forward(x, training=True)
-            out, pred, _ = e.head(z, label, 1, want_grad=True)
-            e.encoder_backward(x)
-        torch.cuda.synchronize()
+        e.lib.cp_debug_set_option(b"fp8_bridge", 1 if mode == "bridge" else 0)
+        try:
+            for _ in range(3):                     # (the third step runs with scales calibrated by the first two, gradients included)
+                e.step_count = 0                   # same dropout masks in every pass and in both modes
+                e.grads.flat.zero_()
+                z = e.encoder_forward(x, training=True)
+                out, pred, _ = e.head(z, label, 1, want_grad=True)
+                e.encoder_backward(x)
+            torch.cuda.synchronize()
+        finally:
+            e.lib.cp_debug_set_option(b"fp8_bridge", 0)
         grads[mode] = {k: v.clone().cpu().double() for k, v in e.grads.views.items()}
         assert all(bool(torch.isfinite(v).all()) for v in grads[mode].values()), mode
     worst = (1.0, "")

@@ -188,18 +188,26 @@ def _shift_w(t, d):
     return out
 
 
-def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
+def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
+    """every kernel of one training step against a plain torch fp32 recomputation of ITS output from ITS OWN stored inputs, at
+    n_groups groups, with or without dropout (p_drop = 0: every data gradient is the BatchNorm-fused kind).  Also run by
+    tests/test_gpu_ws_kernels.py at a size with ragged tiles."""
+    B, N, P_DROP = n_groups, T * n_groups, p_drop
+    drop = p_drop > 0
     from contrastiveprosthetics_amd import _lib
     from contrastiveprosthetics_amd.engine import Engine
     adabn = False
-    e = Engine(adabn=adabn, dtype="bf16", dp_emg=P_DROP, device="cuda", seed=1000)
+    e = Engine(adabn=adabn, dtype=dtype, dp_emg=P_DROP, device="cuda", seed=1000)
     e.init_parameters(5)
     gen = torch.Generator().manual_seed(9)
     bnn = _bn_names(adabn)
     for b in bnn:                                                   # non-trivial affine: fold / dgamma / dbeta matter
         e.values.views[b + ".weight"].copy_((1.0 + 0.2 * torch.randn(e.values.views[b + ".weight"].shape, generator=gen)).cuda())
         e.values.views[b + ".bias"].copy_((0.1 * torch.randn(e.values.views[b + ".bias"].shape, generator=gen)).cuda())
-    x, labels = synthetic(seed=6)
+    g_ = torch.Generator().manual_seed(data_seed)
+    mu_ = torch.randn(T, 12, generator=g_)
+    x = (mu_[None, :, :] + torch.randn(B, T, 12, generator=g_)).reshape(N, 12).cuda()
+    labels = torch.arange(T).repeat(B).cuda()
     tap = torch.zeros(9, N, 768, dtype=torch.bfloat16, device="cuda")
     lib = _lib.load()
     _lib.check(lib.cp_debug_set_grad_tap(tap.data_ptr(), tap.numel() * 2), "cp_debug_set_grad_tap")
@@ -214,7 +222,7 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
     W = e.values.views
     G = e.grads.views
     report = {}
-    inv_keep = 1.0 / (1.0 - round(P_DROP * 65536) / 65536.0)
+    inv_keep = 1.0 / (1.0 - round(P_DROP * 65536) / 65536.0) if drop else 1.0
     ACT_MAX, ACT_RMS, PGRAD = 1.2e-2, 8e-3, 5e-5
 
     def check_tensor(name, got, ref, mx=ACT_MAX, rms=ACT_RMS):
@@ -249,7 +257,7 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
     for i, li in enumerate(LIN):
         Lp = i + 1
         s = st[Lp]
-        if Lp >= 5:
+        if drop and Lp >= 5:
             bn = prev * s[2] + s[3]
             u = e.debug_activation(9 + Lp - 5)
             keep = (u != 0) | (bn == 0)
@@ -275,9 +283,13 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
         del ref, inp
     s = st[8]
     bn8 = acts[8] * s[2] + s[3]
-    u8 = e.debug_activation(12)
-    masks[8] = (u8 != 0) | (bn8 == 0)
-    check_tensor("fwd/dropout8", u8, bn8 * masks[8] * inv_keep, mx=8e-3, rms=4e-3)
+    if drop:
+        u8 = e.debug_activation(12)
+        masks[8] = (u8 != 0) | (bn8 == 0)
+        check_tensor("fwd/dropout8", u8, bn8 * masks[8] * inv_keep, mx=8e-3, rms=4e-3)
+    else:
+        u8 = bn8.clone()
+        masks[8] = torch.ones_like(bn8, dtype=torch.bool)
     z_ref = u8 @ W["emg_net.last.0.weight"].t()
     a, b = _rel(z, z_ref)
     report["fwd/proj"] = (a, b)
@@ -313,15 +325,17 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
     g_ref = g_ref * (acts[8] > 0)
     check_tensor("bwd/proj_dgrad+bn8 (EPI_DGRAD_ST K=64, bn_relu_bwd)", tap[8].reshape(-1)[:N * 512].reshape(N, 512), g_ref,
                  mx=1.5e-2, rms=9e-3)                               # on top of a bf16-rounded dz
-    check_param("bwd/bn8_gamma", G[bnn[8] + ".weight"], dg, tol=8e-3)
-    check_param("bwd/bn8_beta", G[bnn[8] + ".bias"], db_, tol=8e-3)
+    # (without dropout the sums come from the projection's weight-gradient product, i.e. from the head kernel's bf16-rounded dz,
+    #  while this reference starts from autograd's f32 dz: the same 1e-3 as bwd/last_w above)
+    check_param("bwd/bn8_gamma", G[bnn[8] + ".weight"], dg, tol=8e-3 if drop else 1e-3)
+    check_param("bwd/bn8_beta", G[bnn[8] + ".bias"], db_, tol=8e-3 if drop else 1e-3)
     del gv, g_ref, u8
     for L in range(8, 1, -1):
         i, Lp = L - 2, L - 1
         li = LIN[i]
         gy = tap[L].reshape(-1)[:N * 512].reshape(N, 512).float()   # the kernel's own input: dL/d(pre-activation of fc_i)
         s = st[Lp]
-        if Lp >= 5:
+        if drop and Lp >= 5:
             inp = e.debug_activation(9 + Lp - 5)
         elif Lp == 1:
             inp = (acts[1].reshape(N, 12, 64) * s[2] + s[3]).permute(0, 2, 1).reshape(N, 768)
@@ -331,7 +345,7 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
         check_param(f"bwd/fc{i + 1}_b", G[f"emg_net.linear.{li}.bias"], gy.sum(0))
         del inp
         gin = gy @ W[f"emg_net.linear.{li}.weight"]                 # (N, K) in the reference's input order
-        if Lp >= 5:
+        if drop and Lp >= 5:
             gin = gin * masks[Lp] * inv_keep
             mode = "EPI_DGRAD_ST + bn_relu_bwd"
         else:
@@ -348,8 +362,8 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
         width = 768 if Lp == 1 else 512
         got = tap[Lp].reshape(-1)[:N * width].reshape(g_ref.shape)
         check_tensor(f"bwd/fc{i + 1}_dgrad+bn{Lp} ({mode})", got, g_ref)
-        check_param(f"bwd/bn{Lp}_gamma", G[bnn[Lp] + ".weight"], dg, tol=8e-3 if Lp >= 5 else 1e-5)
-        check_param(f"bwd/bn{Lp}_beta", G[bnn[Lp] + ".bias"], db_, tol=8e-3 if Lp >= 5 else 1e-5)
+        check_param(f"bwd/bn{Lp}_gamma", G[bnn[Lp] + ".weight"], dg, tol=8e-3 if (drop and Lp >= 5) else 1e-5)
+        check_param(f"bwd/bn{Lp}_beta", G[bnn[Lp] + ".bias"], db_, tol=8e-3 if (drop and Lp >= 5) else 1e-5)
         del gin, g_ref, gy
     # conv2: tap[1] = dL/d(conv2 pre-activation) [N][12][64]
     g2 = tap[1].reshape(N, 12, 64).float()
@@ -372,9 +386,15 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
     dw1 = torch.stack([(g0 * xp[:, t:t + 12].unsqueeze(-1)).reshape(-1, 64).sum(0) for t in range(3)], -1)   # (64, 3)
     check_param("bwd/conv1_w", G["emg_net.conv_emg.0.weight"][:, 0, 1, :], dw1)
     assert float(G["emg_net.conv_emg.0.weight"][:, 0, 0, :].abs().max()) == 0.0
-    print("\nbench-config parity (bf16, stock BN, dp 0.0635, 4096 groups): max-err/max-ref [, rms-err/rms-ref]")
+    print(f"\nkernel-by-kernel parity ({dtype}, stock BN, dp {P_DROP}, {B} groups): max-err/max-ref [, rms-err/rms-ref]")
     for k, v in report.items():
         print("  %-62s %s" % (k, "  ".join("%.2e" % t for t in v)))
+
+
+
+
+def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
+    recompute_check(B, P_DROP)
 
 
 def test_bf16_vs_f32_hip_argmax_agreement_at_bench_size():

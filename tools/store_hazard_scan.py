@@ -2,7 +2,8 @@
 """Scan the device assembly of csrc/api.hip for the gfx950 store-data hazard (csrc/gemm_ws.cuh, store_b128_settled): a
 buffer_store_dwordx3/x4 whose data registers are overwritten by one of the next two instructions.  LLVM's hazard recogniser does not
 protect MUBUF stores whose soffset is an SGPR; on gfx950 such a store was seen sending the overwritten values for lanes 12-15 / 44-47.
-usage: tools/store_hazard_scan.py [file.s]   (without a file: compiles csrc/api.hip to assembly first).  Exit code 1 = hazards found."""
+usage: tools/store_hazard_scan.py [--variants] [file.s]   (without a file: compiles csrc/api.hip to assembly first; --variants: with
+-DCP_VARIANTS, i.e. the tools-only build that also carries the superseded kernels whose timings DESIGN.md quotes).  Exit code 1 = hazards found."""
 import os
 import re
 import subprocess
@@ -13,11 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def assembly() -> str:
-    if len(sys.argv) > 1:
-        return open(sys.argv[1]).read()
+    args = [a for a in sys.argv[1:] if a != "--variants"]
+    if args:
+        return open(args[0]).read()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "api.s")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"]
+                       + (["-DCP_VARIANTS"] if "--variants" in sys.argv else []) + [
                         os.path.join(ROOT, "contrastiveprosthetics_amd", "csrc", "api.hip"), "-o", out], check=True, cwd=d,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return open(out).read()
