@@ -1832,7 +1832,14 @@ extern "C" int cp_debug_activation(const cp_config* cfg, const cp_params* p, con
     }
     if (cfg->dtype == CP_FP8) {
         // the stored e4m3 tensor in true units (dropout(BN(fc7)), layer CP_N_BN + 3, is never stored on this path)
-        if (layer == CP_N_BN + 3) return fail(CP_ERR_ARG, "CP_FP8: dropout(BN(fc7)) is formed while staging and never stored");
+        if (layer == CP_N_BN + 3) {
+            // dropout(BN(fc7)) is formed while staging and never stored: computed here in f32 from the stored e4m3 activation, same key
+            hipLaunchKernelGGL(debug_bn_dropout8_f32_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, base + w.act8[8],
+                               (const float*)(base + w.stats[8]), out, cfg->n_windows, 512, dp_thresh(cfg->dp_emg), dp_key(cfg, 8),
+                               dp_inv_keep(cfg->dp_emg), dp_salt(cfg), (const Fp8State*)(base + w.f8state), F8_T_ACT + 8);
+            CKL("debug_bn_dropout8_f32_kernel");
+            return 0;
+        }
         const int t = layer < CP_N_BN ? F8_T_ACT + layer : F8_T_U + (layer - CP_N_BN);
         const uint8_t* src = base + (layer < CP_N_BN ? w.act8[layer] : w.u8[layer - CP_N_BN]);
         hipLaunchKernelGGL(dequant8_f32_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, src, out, n, (const Fp8State*)(base + w.f8state), t);

@@ -748,19 +748,24 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
                 y[2] = rv[2] != 0.f ? y[2] * keep_so : 0.f;
                 y[3] = rv[3] != 0.f ? y[3] * keep_so : 0.f;
             }
+            // (the sums are of the values AS STORED: the bias gradient and the BatchNorm-backward sums derived from it must describe
+            //  the tensor the next kernels read)
+            if constexpr (OUT_BF16) {
+                pk[ft].x = cvt_pk_bf16<false>(y[0], y[1]);
+                pk[ft].y = cvt_pk_bf16<false>(y[2], y[3]);
+                y[0] = __uint_as_float(pk[ft].x << 16); y[1] = __uint_as_float(pk[ft].x & 0xffff0000u);
+                y[2] = __uint_as_float(pk[ft].y << 16); y[3] = __uint_as_float(pk[ft].y & 0xffff0000u);
+            } else {
+                amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
+                amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
+                d[ft] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+                f8_unpack4_e5m2(d[ft], y);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float w = live ? y[e] : 0.f;
                 s1[ft * 4 + e] += w;
                 if constexpr (STATS) s2[ft * 4 + e] = fmaf(w, rv[e], s2[ft * 4 + e]);
-            }
-            if constexpr (OUT_BF16) {
-                pk[ft].x = cvt_pk_bf16<false>(y[0], y[1]);
-                pk[ft].y = cvt_pk_bf16<false>(y[2], y[3]);
-            } else {
-                amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
-                amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
-                d[ft] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
             }
         }
         if constexpr (OUT_BF16) {
@@ -1090,13 +1095,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd8_kernel(uint8_t* __restrict__
             f8_unpack4_e5m2(gw[q], gv);
             f8_unpack4(rw[q], rv);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = rv[e] > 0.f ? fmaf(ca[4 * q + e], gv[e], fmaf(cb[4 * q + e], rv[e], cz[4 * q + e])) : 0.f;
-                sum[4 * q + e] += y[e];
-            }
+            for (int e = 0; e < 4; ++e) y[e] = rv[e] > 0.f ? fmaf(ca[4 * q + e], gv[e], fmaf(cb[4 * q + e], rv[e], cz[4 * q + e])) : 0.f;
             amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
             amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
             o[q] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+            // column sums of the values AS STORED: the next layer's BatchNorm-backward sums are derived from this bias gradient and
+            // from products of the stored tensor (bn_bwd_sums_from_wgrad_kernel), so the two must describe the same numbers
+            f8_unpack4_e5m2(o[q], y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[4 * q + e] += y[e];
         }
         *(uint4*)(g + m * C + cc * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     };
@@ -1259,6 +1266,7 @@ __global__ __launch_bounds__(256, 2) void proj_dgrad8_kernel(Proj8Args a) {
                     amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
                     amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
                     d[ft] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+                    f8_unpack4_e5m2(d[ft], y);                       // (column sums of the values as stored)
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1314,4 +1322,19 @@ static inline hipError_t launch_proj_dgrad8(const Proj8Args& a, hipStream_t st, 
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
     hipLaunchKernelGGL(proj_dgrad8_kernel<PASS>, dim3(blocks), dim3(256), 0, st, a);
     return hipGetLastError();
+}
+
+// test aid (cp_debug_activation): u = dropout(BatchNorm(r)) in f32 from a stored e4m3 activation, the mask of the forward pass
+__global__ void debug_bn_dropout8_f32_kernel(const uint8_t* __restrict__ r, const float* __restrict__ stats, float* __restrict__ out,
+                                             int64_t rows, int C, uint32_t thresh, uint32_t key, float inv_keep, const uint32_t* __restrict__ salt,
+                                             const Fp8State* __restrict__ st, int t_in) {
+    if (salt) key ^= *salt;
+    const float d = f8_exp2i(-st->e[t_in]);
+    const int64_t n = rows * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = (uint32_t)(i / C), f = (uint32_t)(i % C);
+        const uint32_t pr = dropout_pair(key, m, (uint32_t)C, f & ~1u);
+        const float v = __builtin_amdgcn_cvt_f32_fp8((int)r[i], 0) * d;
+        out[i] = fmaf(v, stats[2 * C + f], stats[3 * C + f]) * dropout_scale(pr, (int)(f & 1u), thresh, inv_keep);
+    }
 }

@@ -210,3 +210,45 @@ def test_backward_8bit_against_the_bf16_bridge(dp, B):
     print(f"\n8-bit backward vs bf16 bridge (dp={dp}, B={B}): worst cosine {worst[0]:.4f} at {worst[1]}")
     print("\n".join(report))
     assert not bad, "8-bit vs bridged gradients:\n" + "\n".join(bad)
+
+
+def test_every_8bit_kernel_against_fp32_recompute_at_bench_size():
+    """BASELINE config 4's kernels at config 1's size (4096 groups, dropout on): every stored activation, dropout output, statistic
+    and -- through the gradient tap -- every backward kernel's output against a torch fp32 recomputation from that kernel's OWN
+    stored inputs (tests/test_gpu_fullsize.py, recompute_check), at bars that are the 8-bit formats' rounding steps."""
+    from test_gpu_fullsize import recompute_check
+    recompute_check(4096, 0.0635, dtype="fp8")
+
+
+@pytest.mark.parametrize("groups", [4096, 8192])
+def test_against_the_bf16_path_at_bench_sizes(groups):
+    """same weights, windows and dropout masks through the bf16 and the 8-bit path at config 1's and config 4's per-GPU sizes
+    (4096 / 8192 groups): distances REPORTED; gated on finiteness and on the loss (within 1 %)."""
+    from contrastiveprosthetics_amd.engine import Engine
+    n = groups * T
+    g = torch.Generator().manual_seed(6)
+    mu = torch.randn(T, 12, generator=g)
+    x = (mu[None] + torch.randn(groups, T, 12, generator=g)).reshape(n, 12).cuda()
+    labels = torch.arange(T).repeat(groups).cuda()
+    res = {}
+    for dt in ("bf16", "fp8"):
+        e = Engine(adabn=False, dtype=dt, dp_emg=0.0635, device="cuda", seed=1000)
+        e.init_parameters(5)
+        for _ in range(2):
+            e.step_count = 0
+            z = e.encoder_forward(x, training=True)
+        out, pred, logits = e.head(z, labels, 1, want_grad=True, want_logits=True)
+        e.encoder_backward(x)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(e.grads.flat).all()), dt
+        res[dt] = (float(out[0]), pred.clone(), logits.clone(), e.grads.flat.clone())
+        del e, z
+        torch.cuda.empty_cache()
+    d = (res["fp8"][2] - res["bf16"][2]).abs()
+    agree = float((res["fp8"][1] == res["bf16"][1]).float().mean())
+    ga, gb = res["fp8"][3].double(), res["bf16"][3].double()
+    cos = float(ga @ gb / (ga.norm() * gb.norm()))
+    print(f"\nfp8 vs bf16 at {groups} groups ({n} windows): max |dlogit| {float(d.max()):.3f}, rms {float(d.pow(2).mean().sqrt()):.4f}, argmax agreement "
+          f"{agree:.4f}, loss {res['fp8'][0]:.5f} vs {res['bf16'][0]:.5f}, cosine of the whole gradient {cos:.4f}")
+    assert abs(res["fp8"][0] - res["bf16"][0]) < 0.01 * res["bf16"][0]
+    assert cos > 0.9

@@ -224,13 +224,34 @@ def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
     report = {}
     inv_keep = 1.0 / (1.0 - round(P_DROP * 65536) / 65536.0) if drop else 1.0
     ACT_MAX, ACT_RMS, PGRAD = 1.2e-2, 8e-3, 5e-5
+    FP8 = dtype == "fp8"
+    if FP8:
+        # e4m3 storage (3 mantissa bits: one rounding is up to 2^-4 of the element) and e4m3 weights; gradients are e5m2 (2 bits):
+        # the bars below are the formats' rounding steps, not measurements -- a wrong tile or lane map is off by the values themselves
+        ACT_MAX, ACT_RMS, PGRAD = 0.13, 0.06, 3e-2
 
     def check_tensor(name, got, ref, mx=ACT_MAX, rms=ACT_RMS):
+        if FP8:
+            mx, rms = max(mx, 0.13), max(rms, 0.06)
+            if name.startswith("bwd/"):
+                mx, rms = 0.25, 0.12
         a, b = _rel(got, ref)
         report[name] = (a, b)
         assert a < mx and b < rms, (name, a, b)
 
-    def check_param(name, got, ref, tol=PGRAD):
+    def check_param(name, got, ref, tol=PGRAD, colsum_of=None):
+        if FP8 and colsum_of is not None:
+            # a bias gradient = column sums of an e5m2 tensor AS STORED (the kernels sum the values they have just rounded: the
+            # BatchNorm-backward sums of the next layer are derived from this vector and from products of the stored tensor, so the
+            # two must describe the same numbers.  Summing the values before their rounding differed from this by up to 3 % of
+            # sum |g| per column -- several times the sum itself -- where the input gradient is itself 8-bit: round-to-nearest of
+            # ca g + cb r + cz erases the small mean-removal terms next to an already coarse g.)
+            a = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+            report[name] = (a,)
+            assert a < 2e-4, (name, a)
+            return
+        if FP8 and not name.startswith("head/"):
+            tol = max(tol, 0.15 if ("_b" in name.split("/")[1] or "beta" in name or "gamma" in name) else 3e-2)
         a = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
         report[name] = (a,)
         assert a < tol, (name, a)
@@ -275,9 +296,11 @@ def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
         got = e.debug_activation(2 + i)
         check_tensor(f"fwd/fc{i + 1}", got, ref)
         # the stored statistics are those of the stored activation (biased variance, eps 1e-5)
-        np.testing.assert_allclose(st[2 + i][0].cpu().numpy(), got.mean(0).cpu().numpy(), rtol=2e-4, atol=2e-5)
+        # (fp8: the statistics are of the outputs BEFORE their rounding to e4m3 -- unbiased, so the means agree; the variance of
+        #  the stored values is larger by the rounding noise, ~0.13 % of E[r^2])
+        np.testing.assert_allclose(st[2 + i][0].cpu().numpy(), got.mean(0).cpu().numpy(), rtol=1e-3 if FP8 else 2e-4, atol=1e-4 if FP8 else 2e-5)
         var = got.double().var(0, unbiased=False).float()
-        np.testing.assert_allclose(st[2 + i][1].cpu().numpy(), (1.0 / torch.sqrt(var + 1e-5)).cpu().numpy(), rtol=2e-3)
+        np.testing.assert_allclose(st[2 + i][1].cpu().numpy(), (1.0 / torch.sqrt(var + 1e-5)).cpu().numpy(), rtol=6e-3 if FP8 else 2e-3)
         acts[2 + i] = got
         prev = got
         del ref, inp
@@ -342,7 +365,7 @@ def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
         else:
             inp = acts[Lp] * s[2] + s[3]
         check_param(f"bwd/fc{i + 1}_w ({'paired ' if i in (3, 4, 5, 6) else ''}gemm_tn256)", G[f"emg_net.linear.{li}.weight"], gy.t() @ inp)
-        check_param(f"bwd/fc{i + 1}_b", G[f"emg_net.linear.{li}.bias"], gy.sum(0))
+        check_param(f"bwd/fc{i + 1}_b", G[f"emg_net.linear.{li}.bias"], gy.sum(0), colsum_of=gy)
         del inp
         gin = gy @ W[f"emg_net.linear.{li}.weight"]                 # (N, K) in the reference's input order
         if drop and Lp >= 5:
