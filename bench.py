@@ -175,6 +175,44 @@ def cpu_baseline(seconds: float, threads: int):
                 b8=dict(small, cores=threads, note="BASELINE config 1 batch size (train.py --batch_size 8 --no_adabn)"))
 
 
+def small_batch_record(dev, dtype: str, seconds: float = 0.6):
+    """The same training step at the reference's own batch sizes (code/train.py:185 --batch_size 8; 32 for the HPO sweeps), the kernels of
+    csrc/small.cuh: ms per step issued call by call, inputs resident, a fresh engine per size.  Reported beside cpu_baseline.b8; it is
+    not `value`.  8-bit storage has no small-batch path (its scale state needs a history): bf16 stands in on an fp8 line."""
+    from contrastiveprosthetics_amd.engine import Engine
+    dt = "bf16" if dtype == "fp8" else dtype
+    D = 1800
+    g = torch.Generator().manual_seed(7)
+    table = (torch.randn(T, 1, 12, generator=g) + torch.randn(T, D, 12, generator=g)).reshape(T * D, 12).to(dev)
+    emg_rand = (torch.rand(T, D, generator=g).argsort(-1) + torch.arange(T).reshape(T, 1) * D).to(dev)
+    out = dict(dtype=dt, note="one process, one stream, call by call (tools/graph_bench.py: the same step as one HIP graph)")
+    for Bs in (8, 32):
+        e = Engine(adabn=False, dtype=dt, dp_emg=BEST["dp_emg"], device=dev, seed=1)
+        e.init_parameters(2)
+        perms = [torch.randperm(D, generator=g)[:Bs].to(dev) for _ in range(32)]
+        labels = torch.arange(T).repeat(Bs).to(dev)
+
+        def one(p):
+            x = e.gather(table, emg_rand, p, 1)
+            z = e.encoder_forward(x, training=True)
+            e.head(z, labels, 1, want_grad=True)
+            e.encoder_backward(x)
+            e.adam_step(BEST)
+        for p in perms[:8]:
+            one(p)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds / 2:
+            for p in perms:
+                one(p)
+            torch.cuda.synchronize(dev)
+            n += len(perms)
+        ms = (time.perf_counter() - t0) / n * 1e3
+        out[f"b{Bs}"] = dict(groups=Bs, windows=Bs * T, ms_per_step=ms, windows_per_s=Bs * T / ms * 1e3, steps_timed=n)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,6 +440,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, threads=min(16, os.cpu_count() or 1))
             rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        if world == 1 and not rehearse and args.class_encoder == "onehot":
+            rec["small_batch"] = small_batch_record(dev, args.dtype)
+            if "cpu_baseline" in rec and "b8" in rec["cpu_baseline"]:
+                rec["small_batch"]["b8"]["over_cpu_b8"] = rec["small_batch"]["b8"]["windows_per_s"] / rec["cpu_baseline"]["b8"]["value"]
         print(json.dumps(rec), flush=True)
     if use_dist:
         dist.destroy_process_group()

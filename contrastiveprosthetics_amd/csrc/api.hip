@@ -23,6 +23,7 @@
 #include "preprocess.cuh"
 #include "glove.cuh"
 #include "fp8.cuh"
+#include "small.cuh"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* what) {
@@ -49,6 +50,7 @@ extern "C" int cp_version(void) { return CP_VERSION; }
 struct OptName { const char* name; int CpOptions::*field; };
 static const OptName kOptNames[] = {
     {"unfused_bn_bwd", &CpOptions::unfused_bn_bwd}, {"unpaired_wgrad", &CpOptions::unpaired_wgrad}, {"fp8_bridge", &CpOptions::fp8_bridge},
+    {"no_small", &CpOptions::no_small},
 #ifdef CP_VARIANTS
     {"no_ws", &CpOptions::no_ws}, {"no_wsk", &CpOptions::no_wsk}, {"no_wsd", &CpOptions::no_wsd}, {"no_wsd_st", &CpOptions::no_wsd_st},
     {"staged_r_epilogue", &CpOptions::staged_r_epilogue}, {"ws32", &CpOptions::ws32}, {"wsd32", &CpOptions::wsd32}, {"tn_w4", &CpOptions::tn_w4},
@@ -204,6 +206,7 @@ struct WS {
     size_t slabs;            // f32
     size_t praw;             // f32 [512][768]: raw (un-fixed) weight-gradient product of the current layer
     size_t head_part;        // f32
+    size_t sm_acc;                // i64 [18][2][768]: fixed-point BatchNorm totals of the small-batch form (csrc/small.cuh): forward layers 0..8, backward 9..17
     size_t sync_loc, sync_glob;   // f32 [2][768] each: one row of statistics, this rank's and the sum over ranks (sync BN)
     // CP_FP8 (csrc/fp8.cuh): the scale table (ALWAYS at offset 0, so that it survives a change of n_windows), the e4m3 activations,
     // dropout outputs and fc weights with their scale bytes; the 16-bit buffers above are then what the bf16 backward kernels read
@@ -258,6 +261,7 @@ static WS carve(int64_t N, int dtype, float dp) {
     w.slabs = take(kSlabFloats * 4);
     w.praw = take((size_t)512 * 768 * 4);
     w.head_part = take((size_t)kHeadBlocksMax * HEAD_PART * 4);
+    w.sm_acc = take((size_t)18 * 2 * 768 * 8);
     w.sync_loc = take(2 * 768 * 4);
     w.sync_glob = take(2 * 768 * 4);
     w.total = o;
@@ -701,6 +705,173 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// small batches (csrc/small.cuh): N <= 64 groups, batch statistics, f32 or bf16
+// ---------------------------------------------------------------------------------------
+static unsigned char* g_grad_tap = nullptr;       // test aid, set by cp_debug_set_grad_tap (below)
+static bool use_small(const cp_config* c) {
+    return c->n_windows <= SM_MAX_WINDOWS && (c->training || c->adabn) && c->dtype != CP_FP8 && !g_sync_fn && !g_grad_tap && !g_opt.no_small;
+}
+
+template <typename T>
+static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const cp_bn_buffers* bn, const float* x,
+                                   unsigned char* base, const WS& w, float* z, hipStream_t st) {
+    using D = DT<T>;
+    const int64_t N = c->n_windows, R12 = N * 12;
+    const bool have_running = bn && bn->running_mean[0] && bn->running_var[0];
+    const int upd = (c->training && !c->adabn && have_running) ? 1 : 0;
+    const bool drop = c->training && c->dp_emg > 0.f;
+    float* partials = (float*)(base + w.partials);
+    auto act = [&](int l) { return (T*)(base + w.act[l]); };
+    auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
+    const int tiles_m = (int)((N + SM_BM - 1) / SM_BM);
+    {
+        ProfScope ps(CP_K_PREP, st);
+        hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
+        SmCopyBatch cb{};
+        for (int i = 0; i < CP_N_FC; ++i) cb.job[i] = SmCopyJob{p->fc_w[i], base + w.wfc[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
+        cb.job[CP_N_FC] = SmCopyJob{p->last_w, base + w.wlast, CP_D_E, 512, 32, 0};
+        cb.njobs = CP_N_FC + 1; cb.zero = (long long*)(base + w.sm_acc); cb.nzero = 18 * 2 * 768;
+        hipLaunchKernelGGL((sm_weight_copy_kernel<T>), dim3(512, CP_N_FC + 2), dim3(256), 0, st, cb);
+        CKL("prep kernels (small)");
+    }
+    // conv1 statistics (finalised by their own launch: conv2's kernel reads finished statistics) and conv2
+    {
+        constexpr int RPP = 256 / (64 / D::EPC);
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int g = (int)((need + passes - 1) / passes);
+        ProfScope ps(CP_K_CONV1_FWD, st);
+        hipLaunchKernelGGL((conv1_stats_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, partials, R12);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, partials, g, (double)R12, p->bn_g[0], p->bn_b[0],
+                           have_running ? bn->running_mean[0] : nullptr, have_running ? bn->running_var[0] : nullptr, upd, 0,
+                           c->bn_momentum, c->bn_eps, stats(0), 64, (const int*)nullptr);
+        CKL("conv1 (small)");
+    }
+    {
+        ConvArgs ca{};
+        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0);
+        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = act(1); ca.partials = partials; ca.n_windows = N;
+        const int g2 = conv_grid<T>(N);
+        ProfScope ps(CP_K_CONV2_FWD, st);
+        hipLaunchKernelGGL((conv2_strip_kernel<T, 0>), dim3(g2), dim3(256), 0, st, ca);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, partials, g2, (double)R12, p->bn_g[1], p->bn_b[1],
+                           have_running ? bn->running_mean[1] : nullptr, have_running ? bn->running_var[1] : nullptr, upd, 0,
+                           c->bn_momentum, c->bn_eps, stats(1), 64, (const int*)nullptr);
+        CKL("conv2 (small)");
+    }
+    // fc1..fc7 and the projection: each launch turns its input's two fixed-point totals per column into scale / shift itself
+    long long* accs = (long long*)(base + w.sm_acc);
+    auto acc_of = [&](int l) { return accs + (size_t)l * 2 * 768; };
+    auto bn_of = [&](int l) {
+        SmBN b{};
+        b.acc = l >= 2 ? acc_of(l) : nullptr; b.C = kLayerC[l]; b.count = l < 2 ? (double)R12 : (double)N;
+        b.gamma = p->bn_g[l]; b.beta = p->bn_b[l]; b.stats = stats(l);
+        b.running_mean = have_running ? bn->running_mean[l] : nullptr; b.running_var = have_running ? bn->running_var[l] : nullptr;
+        b.update_running = upd; b.momentum = c->bn_momentum; b.eps = c->bn_eps;
+        return b;
+    };
+    for (int i = 0; i < CP_N_FC; ++i) {
+        const int L = 2 + i, Lp = L - 1, K = fcK(i);
+        SmFwdArgs a{};
+        a.A = act(Lp); a.W = base + w.wfc[i]; a.bias = p->fc_b[i]; a.C = act(L); a.out_acc = acc_of(L);
+        a.bn_in = bn_of(Lp); a.smod = kLayerC[Lp]; a.N = N; a.K = K;
+        if (drop && Lp >= 5) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
+        ProfScope ps(K == 512 ? CP_K_FC_FWD_WS : CP_K_FC_FWD, st);
+        hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0>), dim3(tiles_m * (512 / SM_BN)), dim3(256), 0, st, a);
+        CKL("sm_fc_fwd_kernel");
+    }
+    {
+        SmFwdArgs a{};
+        a.A = act(8); a.W = base + w.wlast; a.C = z; a.bn_in = bn_of(8); a.smod = 512; a.N = N; a.K = 512;
+        if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
+        ProfScope ps(CP_K_PROJ_FWD, st);
+        hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 1>), dim3(tiles_m), dim3(256), 0, st, a);
+        CKL("sm_fc_fwd_kernel<proj>");
+    }
+    return 0;
+}
+
+template <typename T> static int conv_backward_tail(const cp_config*, const cp_params*, const float*, unsigned char*, const WS&, cp_params*, hipStream_t,
+                                                    hipEvent_t, T*, T*, bool, int);
+
+template <typename T>
+static int encoder_backward_small_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
+                                    cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready) {
+    const int64_t N = c->n_windows;
+    const bool drop = c->training && c->dp_emg > 0.f;
+    float* partials = (float*)(base + w.partials);
+    auto act = [&](int l) { return (T*)(base + w.act[l]); };
+    auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
+    const int tiles_m = (int)((N + SM_BM - 1) / SM_BM);
+    {
+        ProfScope ps(CP_K_PREP, st);
+        TransposeBatch tb{};
+        for (int i = 0; i < CP_N_FC; ++i) tb.job[i] = TransposeJob{p->fc_w[i], base + w.wfc_t[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
+        tb.job[CP_N_FC] = TransposeJob{p->last_w, base + w.wlast_t, CP_D_E, 512, 64, 0};
+        hipLaunchKernelGGL((transpose_w_batch_kernel<T>), dim3(128, CP_N_FC + 1), dim3(256), 0, st, tb);
+        CKL("transpose_w_batch_kernel");
+    }
+    long long* accs = (long long*)(base + w.sm_acc);
+    auto gacc_of = [&](int l) { return accs + (size_t)(9 + l) * 2 * 768; };        // totals of (g, g r_l) for layer l's BatchNorm backward
+    T* gb[2] = {(T*)(base + w.gbuf[0]), (T*)(base + w.gbuf[1])};
+    // weight gradients: whole-batch sums per tile up to 256 rows; more rows are split over workgroups (at most 8 splits, each into
+    // its own slab of all the step's weight gradients) and summed by ONE launch at the end
+    // (one split at 8 groups = 328 rows, without slabs and their reduction launch, measured SLOWER: 13.3 us per launch instead of
+    //  10.3 -- the weight-gradient blocks walk all the rows, six steps of a latency-bound loop -- 21 us lost for 12.7 us gained)
+    int splits = (int)((N + 255) / 256);
+    if (splits > 8) splits = 8;
+    int64_t rps = ((N + splits - 1) / splits + 63) / 64 * 64;
+    splits = (int)((N + rps - 1) / rps);
+    const int64_t kSlabStride = (int64_t)1 << 21;
+    float* slabs = (float*)(base + w.slabs);
+    size_t slab_off = 0;
+    SmReduceBatch rb{};
+    rb.splits = splits; rb.slab_stride = kSlabStride;
+    auto grad_dst = [&](float* real, int numel) -> float* {          // where a role-1 block writes split 0 of this tensor
+        if (splits == 1) return real;
+        float* sl = slabs + slab_off;
+        rb.job[rb.njobs++] = SmReduceJob{sl, real, numel};
+        slab_off += (size_t)numel;
+        return sl;
+    };
+    int cur = 0;
+    {
+        SmBwdArgs a{};
+        a.Gin = base + w.dz; a.Wt = base + w.wlast_t; a.Rp = act(8); a.stats_p = stats(8); a.Gout = gb[cur]; a.out_acc = gacc_of(8);
+        a.dW = grad_dst(g->last_w, CP_D_E * 512); a.db = nullptr; a.slab_stride = kSlabStride; a.rows_per_split = rps; a.splits = splits;
+        a.p_valid = CP_D_E; a.N = N; a.K = 512; a.smod = 512; a.wmode = 0; a.n_dgrad = tiles_m * (512 / SM_BN);
+        if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
+        ProfScope ps(CP_K_PROJ_BWD, st);
+        hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
+        CKL("sm_fc_bwd_kernel<proj>");
+    }
+    for (int L = 8; L >= 2; --L) {
+        const int i = L - 2, Lp = L - 1, K = fcK(i);
+        SmBwdArgs a{};
+        a.Gin = gb[cur]; a.R = act(L); a.gsum = gacc_of(L); a.stats = stats(L);
+        a.dgamma = g->bn_g[L]; a.dbeta = g->bn_b[L]; a.Wt = base + w.wfc_t[i]; a.Rp = act(Lp); a.stats_p = stats(Lp);
+        a.Gout = gb[cur ^ 1];
+        if (Lp == 1) a.out_partials = partials;          // fc1: partial rows [tiles_m][2][768] for the conv tail's finalize launch
+        else a.out_acc = gacc_of(Lp);
+        a.dW = grad_dst(g->fc_w[i], 512 * K); a.db = grad_dst(g->fc_b[i], 512);
+        a.slab_stride = kSlabStride; a.rows_per_split = rps; a.splits = splits; a.p_valid = 512;
+        a.N = N; a.K = K; a.smod = kLayerC[Lp]; a.wmode = i == 0 ? 1 : 0; a.n_dgrad = tiles_m * (K / SM_BN);
+        if (drop && Lp >= 5) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
+        ProfScope ps(CP_K_FC_DGRAD, st);
+        hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
+        CKL("sm_fc_bwd_kernel");
+        cur ^= 1;
+    }
+    if (splits > 1) {
+        ProfScope ps(CP_K_REDUCE_SLABS, st);
+        hipLaunchKernelGGL(sm_reduce_grads_kernel, dim3(96, rb.njobs), dim3(256), 0, st, rb);
+        CKL("sm_reduce_grads_kernel");
+    }
+    // `partials` now holds fc1's partial sums [tiles_m][2][768]: the conv tail finalises conv2's BatchNorm backward from them
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gb[cur], gb[cur ^ 1], false, tiles_m);
+}
+
 extern "C" int cp_encoder_forward(const cp_config* cfg, const cp_params* p, const cp_bn_buffers* bn, const float* x,
                                   void* ws, size_t ws_bytes, float* z_out, void* stream) {
     WS w;
@@ -708,6 +879,10 @@ extern "C" int cp_encoder_forward(const cp_config* cfg, const cp_params* p, cons
     if (!p || !x || !z_out) return fail(CP_ERR_ARG, "cp_encoder_forward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
     if (cfg->dtype == CP_FP8) return encoder_forward_fp8(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
+    if (use_small(cfg)) {
+        if (cfg->dtype == CP_BF16) return encoder_forward_small_t<bf16_t>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
+        return encoder_forward_small_t<float>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
+    }
     if (cfg->dtype == CP_BF16)
         return encoder_forward_t<bf16_t>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
     return encoder_forward_t<float>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
@@ -770,17 +945,20 @@ static int head_impl(const cp_config* cfg, const cp_params* p, const float* z, c
     unsigned char* base = (unsigned char*)ws;
     const size_t es = cfg->dtype == CP_F32 ? 4 : 2;
     ProfScope ps(CP_K_HEAD, st);
-    if (want_grad) CK(hipMemsetAsync(base + w.dz, 0, (size_t)cfg->n_windows * 64 * es, st));
+    // (no memset of dz: head_kernel writes whole 64-element rows, zeros in columns 16..63)
     HeadArgs a{};
     a.z = z; a.easy_w = p->easy_w; a.easy_b = p->easy_b; a.labels = labels;
     a.G = n_groups; a.V = V; a.want_grad = want_grad; a.dz_ld = 64; a.dz = base + w.dz;
     a.logits = logits; a.pred = pred; a.partials = (float*)(base + w.head_part);
     a.gneg = gneg;
-    const int blocks = grid_rows(n_groups, HEAD_WAVES, kHeadBlocksMax);
-    if (cfg->dtype != CP_F32)
-        hipLaunchKernelGGL((head_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((head_kernel<float>), dim3(blocks), dim3(256), 0, st, a);
+    const int blocks = grid_rows(n_groups, HEAD_WAVES * (n_groups >= 2048 ? 2 : 1), kHeadBlocksMax);   // (>= 2048 groups: two per wave, half the prologues)
+    if (cfg->dtype != CP_F32) {
+        if (gneg) hipLaunchKernelGGL((head_kernel<bf16_t, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((head_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a);
+    } else {
+        if (gneg) hipLaunchKernelGGL((head_kernel<float, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((head_kernel<float>), dim3(blocks), dim3(256), 0, st, a);
+    }
     CKL("head_kernel");
     int nr = blocks;
     const PreReduce pre{a.partials, (float*)(base + w.partials2), st};
@@ -885,7 +1063,6 @@ extern "C" int cp_emg_normalize(float* seg, int64_t n_rows, const float* mean_st
 // test aid (cp_debug_set_grad_tap): device buffer of 9 slots x n_windows x 768 elements of the compute dtype that receives a
 // copy of every intermediate gradient of the backward pass, so that each backward kernel can be checked on its own
 // inputs at full batch size (tests/test_gpu_fullsize.py).  nullptr (the default) = no copies.
-static unsigned char* g_grad_tap = nullptr;
 static size_t g_grad_tap_bytes = 0;
 extern "C" int cp_debug_set_grad_tap(void* tap, size_t bytes) {
     g_grad_tap = (unsigned char*)tap;
@@ -1017,15 +1194,12 @@ extern "C" int cp_head_glove(const cp_config* cfg, const float* z, const float* 
     unsigned char* gbase = (unsigned char*)gws;
     const size_t es = cfg->dtype == CP_BF16 ? 2 : 4;
     ProfScope ps(CP_K_HEAD, st);
-    if (want_grad) {
-        CK(hipMemsetAsync(base + w.dz, 0, (size_t)cfg->n_windows * 64 * es, st));
-        CK(hipMemsetAsync(gbase + gw.dzg, 0, (size_t)R * 64 * es, st));
-    }
+    // (no memsets of dz / dzg: head_kernel writes whole 64-element rows)
     HeadArgs a{};
     a.z = z; a.labels = labels; a.zg = zg; a.dzg = gbase + gw.dzg; a.dzg_ld = 64;
     a.G = n_groups; a.V = V; a.want_grad = want_grad; a.dz_ld = 64; a.dz = base + w.dz;
     a.logits = logits; a.pred = pred; a.partials = (float*)(base + w.head_part);
-    const int blocks = grid_rows(n_groups, HEAD_WAVES, kHeadBlocksMax);
+    const int blocks = grid_rows(n_groups, HEAD_WAVES * (n_groups >= 2048 ? 2 : 1), kHeadBlocksMax);   // (>= 2048 groups: two per wave, half the prologues)
     if (cfg->dtype == CP_BF16)
         hipLaunchKernelGGL((head_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, a);
     else
@@ -1684,6 +1858,11 @@ extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, 
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !grads) return fail(CP_ERR_ARG, "cp_encoder_backward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
+    if (cfg->dtype != CP_FP8 && use_small(cfg)) {
+        if (cfg->dtype == CP_BF16)
+            return encoder_backward_small_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
+        return encoder_backward_small_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
+    }
     if (cfg->dtype == CP_FP8 && !g_opt.fp8_bridge)
         return encoder_backward_fp8(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
     if (cfg->dtype == CP_FP8) {
@@ -1852,17 +2031,20 @@ extern "C" int cp_debug_activation(const cp_config* cfg, const cp_params* p, con
 #else
     const bool u8_stored = false;
 #endif
-    if (layer == CP_N_BN + 3 && !u8_stored) {
-        // dropout(BN(fc7)) is not stored by the forward pass (its consumers form it while staging): write it now, same key
+    (void)u8_stored;
+    if (layer >= CP_N_BN) {
+        // dropout(BN(.)) is recomputed from the stored activation with the forward pass's key -- bit for bit what the large-batch
+        // forward stores for fc4..fc6, and the only way to see it for fc7 and after a small-batch forward (csrc/small.cuh)
+        const int Lp = 5 + (layer - CP_N_BN);
         const int64_t N = cfg->n_windows;
-        const float* st8 = (const float*)(base + w.stats[8]);
+        const float* stp = (const float*)(base + w.stats[Lp]);
         if (cfg->dtype == CP_BF16)
             hipLaunchKernelGGL((bn_dropout_apply_kernel<bf16_t>), dim3(grid_rows(N, 256 / (512 / 8), 4096)), dim3(256), 0, (hipStream_t)stream,
-                               (const bf16_t*)(base + w.act[8]), st8, (bf16_t*)(base + off), N, 512, dp_thresh(cfg->dp_emg), dp_key(cfg, 8),
+                               (const bf16_t*)(base + w.act[Lp]), stp, (bf16_t*)(base + off), N, 512, dp_thresh(cfg->dp_emg), dp_key(cfg, Lp),
                                dp_inv_keep(cfg->dp_emg), dp_salt(cfg));
         else
             hipLaunchKernelGGL((bn_dropout_apply_kernel<float>), dim3(grid_rows(N, 256 / (512 / 4), 4096)), dim3(256), 0, (hipStream_t)stream,
-                               (const float*)(base + w.act[8]), st8, (float*)(base + off), N, 512, dp_thresh(cfg->dp_emg), dp_key(cfg, 8),
+                               (const float*)(base + w.act[Lp]), stp, (float*)(base + off), N, 512, dp_thresh(cfg->dp_emg), dp_key(cfg, Lp),
                                dp_inv_keep(cfg->dp_emg), dp_salt(cfg));
         CKL("bn_dropout_apply_kernel(debug)");
     }

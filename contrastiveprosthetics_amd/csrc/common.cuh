@@ -21,6 +21,7 @@ struct CpOptions {
     int unfused_bn_bwd = 0;      // BatchNorm + ReLU backward as its own pass behind every data gradient (the f32 path's order)
     int unpaired_wgrad = 0;      // one weight-gradient launch per layer behind a dropout instead of paired launches
     int fp8_bridge = 0;          // CP_FP8: expand the saved 8-bit tensors to bf16 and run the bf16 backward kernels
+    int no_small = 0;            // batches of <= 64 groups on the large-batch kernels instead of the small-batch form (csrc/small.cuh)
 #ifdef CP_VARIANTS
     int no_ws = 0, no_wsk = 0, no_wsd = 0, no_wsd_st = 0, staged_r_epilogue = 0, ws32 = 0, wsd32 = 0, tn_w4 = 0, tn16 = 0,
         materialize_u8 = 0, no_proj_fused = 0;

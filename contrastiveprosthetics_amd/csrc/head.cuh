@@ -5,9 +5,7 @@
 //                                                                             (code/models.py:146-147, 204-207)
 //   pred[g][i] = argmax_j l[i][j]                                             (code/models.py:149)
 // and, when grads are requested, d loss / d z (through the normalisation) and d loss / d E_hat.
-// 41 <= 64 lanes: lane i owns row i (and column i in the column pass); the 41x41 tile moves
-// between the two views through a per-wave LDS tile with an odd pitch (conflict-free both ways);
-// row/column softmax reductions are register loops per lane, group reductions are wave shuffles.
+// (the kernel's lane layout: above head_kernel)
 #pragma once
 #include "common.cuh"
 
@@ -23,7 +21,7 @@ struct HeadArgs {
     int64_t G;               // groups = B*V
     int V;
     int want_grad;
-    int dz_ld;               // row pitch of dz (elements)
+    int dz_ld;               // row pitch of dz (elements): HEAD_LD
     void* dz;                // [N][dz_ld] T (cols 0..15 written)
     float* logits;           // optional [G][41][41]
     int32_t* pred;           // [G][41]
@@ -40,207 +38,318 @@ struct HeadArgs {
 #define GNEG_PART 64         // stride of the {G, H} table of the global-negatives extension
 #define HEAD_PART 704        // 2 + 41*16 = 658 used, padded to a multiple of 64 for reduce_rows_kernel
 
-template <typename T, bool GLOVE = false>
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
-    using D = DT<T>;
-    __shared__ float Eh[HEAD_T][HEAD_D];                 // normalised class table
-    __shared__ float EhW[GLOVE ? HEAD_WAVES : 1][HEAD_T][HEAD_D];   // GLOVE: the group's own normalised class rows
-    __shared__ float EnW[GLOVE ? HEAD_WAVES : 1][HEAD_T + 3];       //        and their norms
-    __shared__ float Ls[HEAD_WAVES][HEAD_T][HEAD_T + 2]; // logits / dlogits tile per wave (odd pitch 43)
-    __shared__ float Zs[HEAD_WAVES][HEAD_T][HEAD_D];     // z_hat rows per wave
-    __shared__ float Cl[HEAD_WAVES][HEAD_T + 3];         // column log-sum-exp per wave
-    __shared__ int Cls[HEAD_WAVES][HEAD_T + 3];          // class of position j in this group
-    __shared__ float dE[HEAD_WAVES][HEAD_T][HEAD_D];     // per-wave accumulator of d/dE_hat (by class)
-    __shared__ float wl[HEAD_WAVES], wc[HEAD_WAVES];
-    __shared__ int Tg[HEAD_T + 3];                       // CE target column of row i = labels[i]
+// ---- the kernel ------------------------------------------------------------------------------------------------------
+// One wavefront per group, the 41x41 tile on the matrix cores (v_mfma_f32_16x16x4_f32, full fp32): lane l = (c = l & 15, q = l >> 4).
+//   A operand: lane supplies A[m = c][k = q];  B operand: B[k = q][n = c];  result: lane holds D[m = 4q + r][n = c], r = 0..3.
+// The tile is padded to 48x48 = 3x3 MFMA tiles and kept in registers TWICE, as L = Z E^T (rows i on (q, r), columns j on c) and as
+// its transpose Lt = E Z^T (rows j on (q, r), columns i on c): a reduction "down the registers and across q" (two xor-shuffles) is the
+// column softmax on L and the row softmax on Lt.  The gradient tile dl is formed ONCE, in L's layout -- where it is, as it stands, the
+// A operand of dE_hat = dl^T Z_hat -- and crosses to the other layout through an LDS tile for dz_hat = dl E_hat.  Logits are carried
+// in log2 units (z_hat is scaled by log2 e on its way into the MFMAs): every exponential is one v_exp_f32 of one subtraction, the
+// loss is converted once per block.  The one-hot terms of dl, [j == y_i] + [i == y_j], are the same for every group: a register tile
+// built once per kernel.
+// Until round 3 every lane walked its row of 41 logits and its column of 41 through LDS with 16 FMAs per logit: 62 us at 4096 groups,
+// 27 us at ONE group per wave (8 groups).
+#define HEAD_LD 64           // row pitch (elements) of dz and dzg: the projection backward kernels contract over 64 columns
+#define HEAD_P 20            // LDS row pitch (floats) of the 48x16 operand tiles: rows 4q + r of the four q land in disjoint bank sets
+#define HEAD_TP 52           // LDS row pitch of the 41x48 dl tile (b128 reads along a row)
+#define HEAD_LOG2E 1.4426950408889634f
+#define HEAD_LN2 0.6931471805599453f
+#define HEAD_PAD (-1e30f)    // a padded logit: finite (0 * pad = 0), its exponentials exactly 0
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < HEAD_T; i += 256) {
-        if constexpr (!GLOVE) {
-            float e[HEAD_D], n = 0.f;
+__device__ __forceinline__ f32x4 head_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float head_qsum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float head_qmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float head_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (arguments <= 0 here, or tiny)
+__device__ __forceinline__ float head_log2(float x) { return __builtin_amdgcn_logf(x); }       // v_log_f32 (arguments in [1, 48])
+
+template <typename T, bool GLOVE = false, bool GNEG = false>
+__global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
+    using D = DT<T>;
+    __shared__ float Eh[HEAD_T][HEAD_D];                               // normalised class table (one-hot path)
+    __shared__ __attribute__((aligned(16))) float Zs[HEAD_WAVES][48][HEAD_P];   // z_hat rows of the wave's group (rows >= 41: zero)
+    __shared__ __attribute__((aligned(16))) float Es[HEAD_WAVES][48][HEAD_P];   // E_hat row of position j of the group
+    __shared__ __attribute__((aligned(16))) float Ts[HEAD_WAVES][HEAD_T][HEAD_TP];   // dl[i][j]
+    __shared__ float Rl[HEAD_WAVES][48];                               // row log2-sum-exp2
+    __shared__ float Nz[HEAD_WAVES][48], En[HEAD_WAVES][48];           // 1/|z_i|, 1/|E_j| (GLOVE)
+    __shared__ float Dz[HEAD_WAVES][48], De[HEAD_WAVES][48];           // z_hat_i . dz_hat_i,  E_hat_j . dE_hat_j
+    __shared__ int Cls[HEAD_WAVES][48];                                // class of position j in this group
+    __shared__ float dE[HEAD_WAVES][HEAD_T][HEAD_D];                   // per-wave accumulator of d/dE_hat (by class): a fixed summation order
+    __shared__ float wl[HEAD_WAVES], wc[HEAD_WAVES];
+    __shared__ int Tg[48];                                             // CE target column of row i = labels[i]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    for (int i = tid; i < 48; i += 256) {
+        if (i < HEAD_T) {
+            if constexpr (!GLOVE) {
+                float e[HEAD_D], n = 0.f;
 #pragma unroll
-            for (int d = 0; d < HEAD_D; ++d) { e[d] = a.easy_w[d * HEAD_T + i] + a.easy_b[d]; n = fmaf(e[d], e[d], n); }
-            n = sqrtf(n);
+                for (int d = 0; d < HEAD_D; ++d) { e[d] = a.easy_w[d * HEAD_T + i] + a.easy_b[d]; n = fmaf(e[d], e[d], n); }
+                n = sqrtf(n);
 #pragma unroll
-            for (int d = 0; d < HEAD_D; ++d) Eh[i][d] = e[d] / n;
+                for (int d = 0; d < HEAD_D; ++d) Eh[i][d] = e[d] / n;
+            }
+            Tg[i] = (int)a.labels[i];
+        } else {
+            Tg[i] = -1;
         }
-        Tg[i] = (int)a.labels[i];
     }
     for (int i = tid; i < HEAD_WAVES * HEAD_T * HEAD_D; i += 256) (&dE[0][0][0])[i] = 0.f;
     __syncthreads();
 
-    const bool act = lane < HEAD_T;
-    const int li = act ? lane : 0;
-    const int tgt = Tg[li];
+    // group-invariant register tiles in L's layout (row i = 16ti + 4q + r, column j = 16tj + c):
+    //   t1 = [j == y_i] (the row loss's target), t2 = [i == y_j] (the column loss's); padded rows and columns carry the target -1
+    // and the padding of the third tile as an additive bias: index 32 + 4q + r past 40 -> HEAD_PAD
+    f32x4 t1[3][3], t2[3][3];
+    float tgc[3], padr[4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) tgc[t] = (float)Tg[16 * t + c];
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + 4 * q + r, yi = Tg[i];
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj) {
+                const int j = 16 * tj + c;
+                t1[ti][tj][r] = (j == yi) ? 1.f : 0.f;
+                t2[ti][tj][r] = (Tg[j] == i) ? 1.f : 0.f;
+                if constexpr (!GNEG) t1[ti][tj][r] += t2[ti][tj][r];    // (one tile: both one-hot terms enter the loss and dl alike)
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) padr[r] = (32 + 4 * q + r < HEAD_T) ? 0.f : HEAD_PAD;
+    const float fq4 = (float)(4 * q);
+    const bool lane_ok2 = 32 + c < HEAD_T;                             // lane-side index of the third tile is a real row / column
     const float cscale = 1.0f / (2.0f * (float)a.G * (float)HEAD_T);
-    float loss_acc = 0.f, corr_acc = 0.f;
+    float loss_acc = 0.f, corr_acc = 0.f;                              // (loss in log2 units)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     for (int64_t g = (int64_t)blockIdx.x * HEAD_WAVES + wave; g < a.G; g += (int64_t)gridDim.x * HEAD_WAVES) {
         const int64_t b = g / a.V;
         const int v = (int)(g % a.V);
-        const int64_t zrow = (b * HEAD_T + li) * a.V + v;
-        if (act) Cls[wave][lane] = GLOVE ? lane : (int)a.labels[b * HEAD_T + lane];
-        if constexpr (GLOVE) {
-            if (act) {
-                const float4* gp = (const float4*)(a.zg + (b * HEAD_T + lane) * HEAD_D);
-                float e[HEAD_D], n = 0.f;
+        // ---- operands: lane (c, q) holds dims 4q..4q+3 of rows 16t + c of Z_hat (times log2 e for the MFMAs) and of E_hat ----------
+        f32x4 zA[3], eA[3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 t4 = gp[q];
-                    e[4 * q] = t4.x; e[4 * q + 1] = t4.y; e[4 * q + 2] = t4.z; e[4 * q + 3] = t4.w;
+        for (int t = 0; t < 3; ++t) {
+            const int i = 16 * t + c;
+            const bool ok = t < 2 || lane_ok2;
+            const int ic = ok ? i : 0;
+            f32x4 z4 = *(const f32x4*)(a.z + ((b * HEAD_T + ic) * a.V + v) * HEAD_D + 4 * q), e4;
+            int cls;
+            if constexpr (GLOVE) { e4 = *(const f32x4*)(a.zg + (b * HEAD_T + ic) * HEAD_D + 4 * q); cls = ic; }
+            else { cls = (int)a.labels[b * HEAD_T + ic]; e4 = *(const f32x4*)&Eh[cls][4 * q]; }
+            const float keep = ok ? 1.f : 0.f;
+            const float iz = 1.0f / sqrtf(head_qsum(fmaf(z4[0], z4[0], fmaf(z4[1], z4[1], fmaf(z4[2], z4[2], z4[3] * z4[3])))));
+            z4 *= iz * keep;
+            if constexpr (GLOVE) {
+                const float ie = 1.0f / sqrtf(head_qsum(fmaf(e4[0], e4[0], fmaf(e4[1], e4[1], fmaf(e4[2], e4[2], e4[3] * e4[3])))));
+                e4 *= ie;
+                if (q == 0) En[wave][i] = ie;
+            }
+            e4 *= keep;
+            zA[t] = z4 * HEAD_LOG2E; eA[t] = e4;
+            *(f32x4*)&Zs[wave][i][4 * q] = z4;
+            *(f32x4*)&Es[wave][i][4 * q] = e4;
+            if (q == 0) { Nz[wave][i] = iz; Cls[wave][i] = cls; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- L[ti][tj][r] = l2[16ti + 4q + r][16tj + c],  Lt[tj][ti][r] = l2[16ti + c][16tj + 4q + r],  l2 = logits * log2 e ------
+        f32x4 L[3][3], Lt[3][3];
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj) {
+                f32x4 x = zero4, y = zero4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x = head_mfma(zA[ti][k], eA[tj][k], x); y = head_mfma(eA[tj][k], zA[ti][k], y); }
+                L[ti][tj] = x; Lt[tj][ti] = y;
+            }
+        // ---- row softmax on Lt (row i = 16ti + c of l lives down the registers (tj, r) and across q) --------------------------------
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti) {
+            float mx = -INFINITY, arg = 0.f;
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (tj == 2) Lt[tj][ti][r] += padr[r];
+                    const float s = Lt[tj][ti][r];
+                    const bool gt = s > mx;
+                    mx = gt ? s : mx;
+                    arg = gt ? (float)(16 * tj + r) + fq4 : arg;
                 }
 #pragma unroll
-                for (int d = 0; d < HEAD_D; ++d) n = fmaf(e[d], e[d], n);
-                n = sqrtf(n);
+            for (int m = 16; m <= 32; m <<= 1) {                       // first maximum: ties go to the smaller column
+                const float om = __shfl_xor(mx, m, 64), oa = __shfl_xor(arg, m, 64);
+                const bool take = om > mx || (om == mx && oa < arg);
+                mx = take ? om : mx;
+                arg = take ? oa : arg;
+            }
+            float se = 0.f;
 #pragma unroll
-                for (int d = 0; d < HEAD_D; ++d) EhW[wave][lane][d] = e[d] / n;
-                EnW[wave][lane] = n;
+            for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) se += head_exp2(Lt[tj][ti][r] - mx);
+            const float rl = mx + head_log2(head_qsum(se));
+            if (q == 0) {
+                const int i = 16 * ti + c;
+                Rl[wave][i] = rl;
+                if (ti < 2 || lane_ok2) {
+                    loss_acc += rl;
+                    corr_acc += (arg == tgc[ti]) ? 1.f : 0.f;
+                    a.pred[g * HEAD_T + i] = (int)arg;
+                }
             }
         }
-        float zh[HEAD_D], nz = 0.f;
-        {
-            const float4* zp = (const float4*)(a.z + zrow * HEAD_D);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 t4 = zp[q];
-                zh[4 * q] = t4.x; zh[4 * q + 1] = t4.y; zh[4 * q + 2] = t4.z; zh[4 * q + 3] = t4.w;
-            }
-#pragma unroll
-            for (int d = 0; d < HEAD_D; ++d) nz = fmaf(zh[d], zh[d], nz);
-            nz = sqrtf(nz);
-#pragma unroll
-            for (int d = 0; d < HEAD_D; ++d) zh[d] = zh[d] / nz;
-        }
-        if (act) {
-#pragma unroll
-            for (int d = 0; d < HEAD_D; ++d) Zs[wave][lane][d] = zh[d];
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- row pass: lane i owns logits[i][:] --------------------------------------
-        // (the 41 logits of the row live in the wave's LDS tile, not in 41 registers: lanes >= 41
-        //  shadow row 0 and never write)
-        float mx = -INFINITY, lt = 0.f;
-        int arg = 0;
-#pragma unroll 4
-        for (int j = 0; j < HEAD_T; ++j) {
-            const float* e = GLOVE ? EhW[wave][j] : Eh[Cls[wave][j]];
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < HEAD_D; ++d) s = fmaf(zh[d], e[d], s);
-            if (act) Ls[wave][lane][j] = s;
-            if (s > mx) { mx = s; arg = j; }
-            if (j == tgt) lt = s;
-        }
-        __builtin_amdgcn_wave_barrier();
-        float se = 0.f;
-#pragma unroll 4
-        // (__expf = one v_exp_f32: the arguments are differences of cosines, in [-2, 0]; the loss and the gradients stay
-        //  within the tolerances of tests/test_gpu_parity.py, 2e-6 on the loss; 164 exponentials per lane and group: 72 -> 62 us)
-        for (int j = 0; j < HEAD_T; ++j) se += __expf(Ls[wave][li][j] - mx);
-        const float lse = mx + logf(se);
-        if (act) {
-            loss_acc += lse - lt;
-            corr_acc += (arg == tgt) ? 1.f : 0.f;
-            a.pred[g * HEAD_T + lane] = arg;
-        }
-        __builtin_amdgcn_wave_barrier();
         if (a.logits != nullptr) {
             float* lo = a.logits + g * (HEAD_T * HEAD_T);
-            for (int i = lane; i < HEAD_T * HEAD_T; i += 64) lo[i] = Ls[wave][i / HEAD_T][i % HEAD_T];
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ti + 4 * q + r, j = 16 * tj + c;
+                        if (i < HEAD_T && j < HEAD_T) lo[i * HEAD_T + j] = L[ti][tj][r] * HEAD_LN2;
+                    }
         }
-        // ---- column pass: lane j owns logits[:][j] -----------------------------------
-        if (a.gneg == nullptr) {
-            float cm = -INFINITY;
-#pragma unroll 4
-            for (int i = 0; i < HEAD_T; ++i) cm = fmaxf(cm, Ls[wave][i][li]);
-            float cs = 0.f;
-#pragma unroll 4
-            for (int i = 0; i < HEAD_T; ++i) cs += __expf(Ls[wave][i][li] - cm);
-            const float clse = cm + logf(cs);
-            if (act) {
-                Cl[wave][lane] = clse;
-                loss_acc += clse - Ls[wave][tgt][lane];      // column j's target row is labels[j]
+        // ---- column pass on L (column j = 16tj + c); the padded rows of the third row tile go to HEAD_PAD for good ----------------------
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) L[2][tj][r] += padr[r];
+        float ccl[3], cch[3];
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj) {
+            const bool jok = tj < 2 || lane_ok2;
+            float cl, ch = 0.f;
+            if constexpr (!GNEG) {
+                float cm = -INFINITY;
+#pragma unroll
+                for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cm = fmaxf(cm, L[ti][tj][r]);
+                cm = head_qmax(cm);
+                float cs = 0.f;
+#pragma unroll
+                for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cs += head_exp2(L[ti][tj][r] - cm);
+                cl = cm + head_log2(head_qsum(cs));
+                loss_acc += (q == 0 && jok) ? cl : 0.f;                // (minus the target logit: the element-wise pass below)
+            } else {
+                // global negatives: the column of class k = Cls[j] sees its positive (row labels[j] of this group) and, through
+                // G[k], every window of another class in the GLOBAL batch:  -pos + log(exp(pos) + G[k])
+                float pos = 0.f;
+#pragma unroll
+                for (int ti = 0; ti < 2 + 1; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pos = fmaf(t2[ti][tj][r], L[ti][tj][r], pos);
+                pos = head_qsum(pos);
+                const int k = Cls[wave][jok ? 16 * tj + c : 0];
+                cl = head_log2(head_exp2(pos) + a.gneg[k]);
+                ch = a.gneg[GNEG_PART + k];
+                loss_acc += (q == 0 && jok) ? cl - pos : 0.f;
             }
-        } else if (act) {
-            // global negatives: the column of class c = Cls[j] sees its positive (row tgt of this group) and, through
-            // G[c], every window of another class in the GLOBAL batch:  -pos + log(exp(pos) + G[c])
-            const float pos = Ls[wave][tgt][lane];
-            const float den = __expf(pos) + a.gneg[Cls[wave][lane]];
-            Cl[wave][lane] = logf(den);                      // log of the column's denominator
-            loss_acc += logf(den) - pos;
+            ccl[tj] = cl; cch[tj] = ch;
+        }
+        // the target logits of the row loss (l[i][labels[i]]) and of the per-group column loss (l[labels[j]][j])
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    loss_acc = fmaf(-t1[ti][tj][r], L[ti][tj][r], loss_acc);
+                }
+        __builtin_amdgcn_wave_barrier();
+        if (!a.want_grad) continue;
+        // ---- dl = c * (P_row + P_col - [j == y_i] - [i == y_j]); a padded element's exponentials are exactly 0 -----------------------
+        f32x4 dzh[3] = {zero4, zero4, zero4}, dEp[3] = {zero4, zero4, zero4};
+        float dote[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + 4 * q + r;                     // row i on (q, r), column j = 16tj + c
+                const bool iok = ti < 2 || 4 * q + r < HEAD_T - 32;
+                const float rl = Rl[wave][i];
+                const float zB = Zs[wave][i][c];
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) {
+                    const float s = L[ti][tj][r];
+                    float dl = head_exp2(s - rl) - t1[ti][tj][r];
+                    if constexpr (!GNEG) dl += head_exp2(s - ccl[tj]);
+                    // positive of its column: exp(pos)/den - 1; a negative of column class k: exp(l) * H[k], H[k] = the sum over ALL groups
+                    // of the global batch of 1/den (gneg_h_kernel); a row of the column's class that is not its positive cannot occur
+                    else dl += t2[ti][tj][r] != 0.f ? head_exp2(s - ccl[tj]) - 1.f : head_exp2(s) * cch[tj];
+                    dl *= cscale;
+                    if (iok) Ts[wave][iok ? i : 0][16 * tj + c] = dl;
+                    if constexpr (GLOVE) dote[tj] = fmaf(dl, s, dote[tj]);
+                    dEp[tj] = head_mfma(dl, zB, dEp[tj]);              // A[m = c][k = q] = dl[i][16tj + c],  B[k = q][n = c] = z_hat[i][c]
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        // dz_hat = dl E_hat: A[m = c][k = q] = dl[16ti + c][16tj + 4q + r] (four consecutive columns of the LDS tile),
+        //                    B[k = q][n = c] = E_hat[16tj + 4q + r][c];  z_hat_i . dz_hat_i = sum_j dl[i][j] l[i][j]
+        float dotz[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj) {
+            f32x4 dlt[3];
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti) dlt[ti] = *(const f32x4*)&Ts[wave][(ti < 2 || lane_ok2) ? 16 * ti + c : 0][16 * tj + 4 * q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool jok = tj < 2 || 4 * q + r < HEAD_T - 32;
+                const float eB = Es[wave][16 * tj + 4 * q + r][c];
+#pragma unroll
+                for (int ti = 0; ti < 3; ++ti) {
+                    const float dl = (tj == 2 && !jok) ? 0.f : dlt[ti][r];      // (columns 41..47 of the tile hold the padded columns' dl)
+                    dotz[ti] = fmaf(dl, Lt[tj][ti][r], dotz[ti]);
+                    dzh[ti] = head_mfma(dl, eB, dzh[ti]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float dz = head_qsum(dotz[t]) * HEAD_LN2;
+            if (q == 0) Dz[wave][16 * t + c] = dz;
+            if constexpr (GLOVE) {
+                const float de = head_qsum(dote[t]) * HEAD_LN2;
+                if (q == 0) De[wave][16 * t + c] = de;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        if (a.want_grad) {
-            // dl[i][j] = c * (P_row + P_col - [j == y_i] - [i == y_j])
-            float dzh[HEAD_D];
+        // ---- out: dz through the normalisation, dz = (dz_hat - z_hat (z_hat . dz_hat)) / |z|; rows are 64 wide for the projection's
+        //      backward kernels, which contract over all 64: columns 16..63 are written as zeros here (no memset launch)
+        const T zero_t = (T)0;
 #pragma unroll
-            for (int d = 0; d < HEAD_D; ++d) dzh[d] = 0.f;
-            const float inv_se = 1.0f / se;
-#pragma unroll 4
-            for (int j = 0; j < HEAD_T; ++j) {
-                const float lj = Ls[wave][li][j];
-                float dl = __expf(lj - mx) * inv_se - ((j == tgt) ? 1.f : 0.f);
-                if (a.gneg == nullptr) {
-                    dl += __expf(lj - Cl[wave][j]) - ((Tg[j] == li) ? 1.f : 0.f);
-                } else {
-                    // positive of its column: exp(pos)/den - 1; a negative of column class c: exp(l) * H[c], H[c] = the sum over
-                    // ALL groups of the global batch of 1/den (gneg_h_kernel); a row of the same class as the column that is
-                    // not its positive cannot occur (one window per class and group)
-                    dl += (Tg[j] == li) ? __expf(lj - Cl[wave][j]) - 1.f : __expf(lj) * a.gneg[GNEG_PART + Cls[wave][j]];
-                }
-                dl *= cscale;
-                const float* e = GLOVE ? EhW[wave][j] : Eh[Cls[wave][j]];
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int d = 0; d < HEAD_D; ++d) dzh[d] = fmaf(dl, e[d], dzh[d]);
-                if (act) Ls[wave][lane][j] = dl;      // own row, read above: the tile now holds dlogits
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (act) {
-                // through the normalisation: dz = (dzh - zh (zh.dzh)) / |z|
-                float dot = 0.f;
-#pragma unroll
-                for (int d = 0; d < HEAD_D; ++d) dot = fmaf(zh[d], dzh[d], dot);
-                float o[HEAD_D];
-#pragma unroll
-                for (int d = 0; d < HEAD_D; ++d) o[d] = (dzh[d] - zh[d] * dot) / nz;
-                T* dst = (T*)a.dz + zrow * a.dz_ld;
-#pragma unroll
-                for (int c = 0; c < HEAD_D / D::EPC; ++c) *(uint4*)(dst + c * D::EPC) = D::pack(o + c * D::EPC);
-            }
-            __builtin_amdgcn_wave_barrier();
-            // d/dE_hat[class of j] += sum_i dl[i][j] * z_hat[i]      (lane j owns column j)
-            if (act) {
-                float accd[HEAD_D];
-#pragma unroll
-                for (int d = 0; d < HEAD_D; ++d) accd[d] = 0.f;
-#pragma unroll 4
-                for (int i = 0; i < HEAD_T; ++i) {
-                    const float dl = Ls[wave][i][lane];
-#pragma unroll
-                    for (int d = 0; d < HEAD_D; ++d) accd[d] = fmaf(dl, Zs[wave][i][d], accd[d]);
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * t + 4 * q + r;
+                if (t == 2 && i >= HEAD_T) continue;
+                {
+                    const float o = (dzh[t][r] - Zs[wave][i][c] * Dz[wave][i]) * Nz[wave][i];
+                    T* dst = (T*)a.dz + ((b * HEAD_T + i) * a.V + v) * HEAD_LD + c;
+                    D::store(dst, o);
+                    dst[16] = zero_t; dst[32] = zero_t; dst[48] = zero_t;
                 }
                 if constexpr (GLOVE) {
-                    // position j's embedding belongs to this group alone: through its normalisation, straight out
-                    float dot = 0.f;
-#pragma unroll
-                    for (int d = 0; d < HEAD_D; ++d) dot = fmaf(EhW[wave][lane][d], accd[d], dot);
-                    float o[HEAD_D];
-#pragma unroll
-                    for (int d = 0; d < HEAD_D; ++d) o[d] = (accd[d] - EhW[wave][lane][d] * dot) / EnW[wave][lane];
-                    T* dst = (T*)a.dzg + (b * HEAD_T + lane) * a.dzg_ld;
-#pragma unroll
-                    for (int c = 0; c < HEAD_D / D::EPC; ++c) *(uint4*)(dst + c * D::EPC) = D::pack(o + c * D::EPC);
+                    // position i's embedding belongs to this group alone: through its normalisation, straight out
+                    const float o = (dEp[t][r] - Es[wave][i][c] * De[wave][i]) * En[wave][i];
+                    T* dst = (T*)a.dzg + (b * HEAD_T + i) * HEAD_LD + c;
+                    D::store(dst, o);
+                    dst[16] = zero_t; dst[32] = zero_t; dst[48] = zero_t;
                 } else {
-                    const int c = Cls[wave][lane];
-#pragma unroll
-                    for (int d = 0; d < HEAD_D; ++d) atomicAdd(&dE[wave][c][d], accd[d]);
+                    atomicAdd(&dE[wave][Cls[wave][i]][c], dEp[t][r]);  // d/dE_hat[class of position i]
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-        }
+        __builtin_amdgcn_wave_barrier();
     }
-    loss_acc = wave_sum(act ? loss_acc : 0.f);
-    corr_acc = wave_sum(act ? corr_acc : 0.f);
+    loss_acc = wave_sum(loss_acc) * HEAD_LN2;
+    corr_acc = wave_sum(corr_acc);
     if (lane == 0) { wl[wave] = loss_acc; wc[wave] = corr_acc; }
     __syncthreads();
     float* part = a.partials + (int64_t)blockIdx.x * HEAD_PART;

@@ -118,7 +118,9 @@ def test_fused_step_equals_reference_style_step():
                 step = sa[k].cpu() - sd[k]
                 diff = (sa[k] - sb[k]).cpu()
                 if s == 0:
-                    assert float(diff.abs().max()) <= 1e-4 * float(step.abs().max()) + 1e-9, k
+                    # (+ one ulp of the parameter itself: a BatchNorm gamma sits at 1.0, where an ulp is 1.2e-7 -- more than 1e-4 of
+                    #  an Adam step of 1e-3 -- and torch's update and the fused kernel's round their last operation differently)
+                    assert float(diff.abs().max()) <= 1e-4 * float(step.abs().max()) + 1.2e-7 * float(sa[k].abs().max().cpu()) + 1e-9, k
                 else:
                     assert float(diff.norm()) <= 3e-2 * float(step.norm()) + 1e-9, k
     for k in sa:

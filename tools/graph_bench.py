@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Steps per second of the training step at the reference's own batch sizes, issued call by call and replayed as one HIP
-graph (engine.GraphStep).  usage: python tools/graph_bench.py [batch ...]   (default 8 32 128)"""
+graph (engine.GraphStep).  usage: python tools/graph_bench.py [batch ...]   (default 8 32 64 128)
+CP_GB_DTYPE=f32|bf16 (default bf16); CP_GB_NO_SMALL=1: batches of <= 64 groups on the large-batch kernels (cp_debug_set_option "no_small")."""
 import os
 import sys
 import time
@@ -16,12 +17,14 @@ D = 1800
 g = torch.Generator().manual_seed(0)
 table = (torch.randn(T, 1, 12, generator=g) + torch.randn(T, D, 12, generator=g)).reshape(T * D, 12).cuda()
 emg_rand = (torch.rand(T, D, generator=g).argsort(-1) + torch.arange(T).reshape(T, 1) * D).cuda()
-for B in [int(a) for a in sys.argv[1:]] or [8, 32, 128]:
+DT = os.environ.get("CP_GB_DTYPE", "bf16")
+for B in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128]:
     perms = [torch.randperm(D, generator=g)[:B].cuda() for _ in range(64)]
     labels = torch.arange(T).repeat(B).cuda()
     res = {}
     for mode in ("calls", "graph"):
-        e = Engine(adabn=False, dtype="bf16", dp_emg=BEST["dp_emg"], device="cuda", seed=1)
+        e = Engine(adabn=False, dtype=DT, dp_emg=BEST["dp_emg"], device="cuda", seed=1)
+        e.lib.cp_debug_set_option(b"no_small", 1 if os.environ.get("CP_GB_NO_SMALL") else 0)
         e.init_parameters(2)
         gs = GraphStep(e, table, emg_rand, B, BEST) if mode == "graph" else None
 
@@ -45,5 +48,5 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 32, 128]:
             torch.cuda.synchronize()
             n += len(perms)
         res[mode] = (time.perf_counter() - t0) / n
-    print(f"batch {B:4d} groups ({B * T:6d} windows): {res['calls'] * 1e3:6.3f} ms/step call by call, {res['graph'] * 1e3:6.3f} ms/step "
+    print(f"{DT}{' (large-batch kernels)' if os.environ.get('CP_GB_NO_SMALL') else ''} batch {B:4d} groups ({B * T:6d} windows): {res['calls'] * 1e3:6.3f} ms/step call by call, {res['graph'] * 1e3:6.3f} ms/step "
           f"as one graph  (x{res['calls'] / res['graph']:.2f};  {B * T / res['graph'] / 1e6:.2f} M windows/s)")

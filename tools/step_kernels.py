@@ -7,8 +7,14 @@ import os
 import sqlite3
 import sys
 
-db = glob.glob(os.path.join(sys.argv[1], "**", "*_results.db"), recursive=True)[0]
-rows = list(sqlite3.connect(db).execute("select name, start, end, duration from kernels order by start"))
+csvs = glob.glob(os.path.join(sys.argv[1], "**", "*_kernel_trace.csv"), recursive=True)
+if csvs:                                            # (--output-format csv)
+    import csv
+    rows = sorted(((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                   for r in csv.DictReader(open(max(csvs, key=os.path.getmtime)))), key=lambda r: r[1])
+else:
+    db = glob.glob(os.path.join(sys.argv[1], "**", "*_results.db"), recursive=True)[0]
+    rows = list(sqlite3.connect(db).execute("select name, start, end, duration from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if r[0].startswith("gather_groups")]
 a, b = idx[-2], idx[-1]
 tot = collections.defaultdict(lambda: [0, 0.0])
