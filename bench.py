@@ -224,15 +224,23 @@ def main():
     ap.add_argument("--dp_emg", type=float, default=BEST["dp_emg"])
     ap.add_argument("--cpu_seconds", type=float, default=15.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--main_only", action="store_true",
+                    help="profiling runs (tools/profile_round.sh): the timed region alone -- no CPU baseline, no other_steps, no small_batch")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass: per-kernel-kind times to stderr")
     ap.add_argument("--profile_every", type=int, default=20,
                     help="bracket the fc GEMM launches with HIP events (the live roofline numbers) on every n-th timed step")
-    ap.add_argument("--global_negatives", default="auto", choices=["auto", "on", "off"],
-                    help="auto: on when N > 1 (BASELINE config[2] names the z all-gather; it must have a reader), off at N = 1")
+    ap.add_argument("--global_negatives", default="auto", choices=["auto", "on", "gather", "reduce", "off"],
+                    help="auto: gather when N > 1 (BASELINE config[2] names the z all-gather; it must have a reader), off at N = 1 (config[1]: "
+                         "the reference's per-group loss).  on = gather.  reduce: the same {G, H} table from per-rank partial sums and two "
+                         "64-float all-reduces (cp_global_negatives_g / _h): no z moves.  Whatever is chosen, the line also carries the "
+                         "other workloads' step times from a second, shorter timed region (`other_steps`), so that the N = 1 and N > 1 "
+                         "lines of a scaling run hold one workload between them")
     ap.add_argument("--sync_bn", action="store_true", help="BatchNorm statistics over the global batch (18 small all-reduces per step)")
     ap.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],
                     help="glove = BASELINE config 3 (glove-angle class encoder); the default line is config 1 (one-hot)")
     args = ap.parse_args()
+    if args.main_only:
+        args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -277,8 +285,11 @@ def main():
     labels = torch.arange(T).repeat(B).to(dev)
     total = args.warmup + args.steps + 2
     perms = [torch.randperm(D, generator=g)[:B].to(dev) for _ in range(total)]
-    gneg = args.class_encoder == "onehot" and (args.global_negatives == "on" or (args.global_negatives == "auto" and use_dist))
-    z_all = torch.empty(world * N, 16, device=dev) if (use_dist and gneg) else None
+    gn = {"on": "gather", "auto": "gather" if use_dist else "off"}.get(args.global_negatives, args.global_negatives)
+    if args.class_encoder != "onehot":
+        gn = "off"
+    gneg = gn != "off"
+    z_all = torch.empty(world * N, 16, device=dev) if (use_dist and args.class_encoder == "onehot") else None
     if args.sync_bn and use_dist:
         eng.set_sync_bn(lambda t: dist.all_reduce(t), world)
     state = {}
@@ -292,16 +303,20 @@ def main():
         from contrastiveprosthetics_amd.dist import GradAllReduce
         reduce_grads = GradAllReduce(eng, force=True)
 
-    def step(i):
+    def step(i, mode=None):
+        mode = mode or gn
         x = eng.gather(table, emg_rand, perms[i], 1)
         z = eng.encoder_forward(x, training=True)
         gh = None
-        if gneg:
+        if mode == "gather":
             # global-batch z matrix over xGMI (north_star): every rank's rows, rank-major; its reader is the column
             # direction of the loss (all windows of other classes in the global batch are negatives)
             if use_dist:
                 dist.all_gather_into_tensor(z_all, z)
             gh = eng.global_negatives(z_all if use_dist else z, labels)
+        elif mode == "reduce":
+            # the same table from per-rank partial sums: two 256-byte all-reduces, no z moves
+            gh = eng.global_negatives(z, labels, all_reduce=(lambda t: dist.all_reduce(t)) if use_dist else (lambda t: t))
         if glove_rows is not None:
             zg = eng.glove_forward(glove_rows, training=True)
             out, pred, _ = eng.head_glove(z, zg, labels, 1, want_grad=True)
@@ -352,6 +367,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss, correct = [float(v) for v in state["out"].tolist()]
+
+    # the other loss workloads on the same engine, shorter: one scaling run's N = 1 and N > 1 lines then hold a common step
+    other_steps = {}
+    if args.class_encoder == "onehot" and not args.main_only:
+        k_other = max(4, args.steps // 2)
+        for mode in ("off", "gather", "reduce"):
+            if mode == gn:
+                continue
+            for i in range(2):
+                step(i, mode)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(k_other):
+                step(args.warmup + (i % args.steps), mode)
+            barrier()
+            el = time.perf_counter() - t1
+            if use_dist:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            other_steps[mode] = dict(ms_per_step=1e3 * el / k_other, value=world * N * k_other / el, steps=k_other,
+                                     loss={"off": "reference per-group loss", "gather": "global negatives, z all-gather",
+                                           "reduce": "global negatives, partial sums + two 64-float all-reduces"}[mode])
 
     if args.breakdown and rank == 0:
         eng.profile_enable(None, max_records=4096)
@@ -428,19 +466,23 @@ def main():
                                         f"({N} windows/GPU/step), {'AdaBN' if args.adabn else 'stock BN (--no_adabn)'}, "
                                         f"dp_emg={args.dp_emg}, d_e=16, random-init weights",
                                global_batch_groups=world * B, windows_per_step=world * N,
-                               parallelism=f"dp{world}" + ((" + z all-gather" if gneg else "") + " + flat-gradient all-reduce (RCCL)"
+                               parallelism=f"dp{world}" + ((" + z all-gather" if gn == "gather" else " + {G,H} all-reduce" if gn == "reduce" else "") + " + flat-gradient all-reduce (RCCL)"
                                                            + (" + synchronised BatchNorm" if args.sync_bn else "") if world > 1 else ""),
-                               loss="global negatives (class->EMG direction over the gathered z)" if gneg else "reference per-group loss",
+                               loss={"gather": "global negatives (class->EMG direction over the gathered z)",
+                                     "reduce": "global negatives (partial sums + two 64-float all-reduces, no z all-gather)",
+                                     "off": "reference per-group loss"}[gn],
                                tile_schedule="dynamic" if eng.lib.cp_get_tile_schedule() else "static"),
                    loss=loss, train_acc=correct / N, roofline=roof,
                    steps_spread=dict(min_ms=step_ms[0], median_ms=step_ms[len(step_ms) // 2], max_ms=step_ms[-1],
                                      note="per-step HIP events on the launch stream, rank 0"))
+        if other_steps:
+            rec["other_steps"] = other_steps
         if rehearse:
             rec["rehearsal"] = f"ranks share one GPU over {rehearse}: control-flow check only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, threads=min(16, os.cpu_count() or 1))
             rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
-        if world == 1 and not rehearse and args.class_encoder == "onehot":
+        if world == 1 and not rehearse and args.class_encoder == "onehot" and not args.main_only:
             rec["small_batch"] = small_batch_record(dev, args.dtype)
             if "cpu_baseline" in rec and "b8" in rec["cpu_baseline"]:
                 rec["small_batch"]["b8"]["over_cpu_b8"] = rec["small_batch"]["b8"]["windows_per_s"] / rec["cpu_baseline"]["b8"]["value"]

@@ -92,10 +92,14 @@ def main():
             wb = w[k][0] / max(w[k][1], 1) * 1024 if k in w else 0.0
             out[k] = dict(launches=int(max(f[k][1] if k in f else 0, w[k][1] if k in w else 0)),
                           read_bytes_per_launch=fb, write_bytes_per_launch=wb, hbm_bytes_per_launch=fb + wb)
+        # the step's own kernels: bench.py's copy-rate measurement (__amd_rocclr_copyBuffer, 1 GiB copies after the timed region) and
+        # torch's fills are not part of a training step; gather_groups_kernel runs once per step
+        step_k = {k: v for k, v in out.items() if not k.startswith("__amd_rocclr") and "at::native" not in k}
+        tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in step_k.values())
+        steps = max([v["launches"] for k, v in out.items() if k.startswith("gather_groups_kernel")] or [0])
         json.dump(dict(note="2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950 correction, separate PMC passes)",
-                       kernels=out), open(sys.argv[4], "w"), indent=1)
-        tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
-        print("total HBM bytes over the profiled run: %.2f GB" % (tot / 1e9))
+                       steps_profiled=steps, hbm_bytes_per_step=tot / steps if steps else None, kernels=out), open(sys.argv[4], "w"), indent=1)
+        print("HBM bytes of the step's kernels over the profiled run: %.2f GB in %d steps = %.2f GB/step" % (tot / 1e9, steps, tot / 1e9 / max(steps, 1)))
     elif mode == "mfma":
         d = sys.argv[2]
         cc = one(os.path.join(d, "**", "*_counter_collection.csv"), required=False)
@@ -108,12 +112,13 @@ def main():
             g = gui[k][0] / max(gui[k][1], 1) if k in gui else 0.0
             if b <= 0:
                 continue
-            per = 16.0 if ("gemm_ws16" in k or "gemm_wsd16" in k) else 32.0          # the 16x16x32 kernels: half the passes
+            # busy cycles per instruction: 16x16x32 bf16 = 16, 32x32x16 bf16 = 32, MX 16x16x128 e4m3 = 32, MX 32x32x64 (gemm_tn8) = 64
+            per = 16.0 if ("gemm_ws16" in k or "gemm_wsd16" in k) else 64.0 if "gemm_tn8" in k else 32.0
             out[k] = dict(launches=int(n), mfma_busy_cycles_per_launch=b, mfma_instructions_per_launch=b / per,
                           gui_active_per_launch=g, sq_busy_cycles_per_launch=sq[k][0] / max(sq[k][1], 1) if k in sq else None,
                           mfma_busy_frac=(b / ((g / 8.0) * 1024.0)) if g > 0 else None)
         json.dump(dict(note="SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 1024 SIMDs) per launch; busy / 32 = MFMA instructions "
-                            "(v_mfma_f32_32x32x16_bf16; busy / 16 for the v_mfma_f32_16x16x32_bf16 kernels gemm_ws16 / gemm_wsd16)", kernels=out), open(sys.argv[3], "w"), indent=1)
+                            "(v_mfma_f32_32x32x16_bf16 and the MX 16x16x128 e4m3 form; busy / 16 for the v_mfma_f32_16x16x32_bf16 kernels gemm_ws16 / gemm_wsd16, busy / 64 for gemm_tn8's MX 32x32x64)", kernels=out), open(sys.argv[3], "w"), indent=1)
         for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"])[:8]:
             print("%-60s busy frac %s  MFMAs/launch %.3g" % (k[:60], "%.3f" % v["mfma_busy_frac"] if v["mfma_busy_frac"] else "n/a",
                                                               v["mfma_instructions_per_launch"]))
