@@ -67,6 +67,8 @@ SYMBOLS = {
                           _fp, _fp, _fp, _P(cp_params), _fp]),
     "cp_global_negatives_scratch_floats": (C.c_size_t, [C.c_int64]),
     "cp_global_negatives": (C.c_int, [_P(cp_params), _fp, C.c_int64, _fp, _fp, _fp, _fp]),
+    "cp_global_negatives_g": (C.c_int, [_P(cp_params), _fp, C.c_int64, _fp, _fp, _fp, _fp]),
+    "cp_global_negatives_h": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp]),
     "cp_head_gneg": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t,
                                _fp, _fp, _fp, _P(cp_params), _fp, _fp]),
     "cp_set_stats_allreduce": (C.c_int, [_fp, _fp, C.c_int32]),

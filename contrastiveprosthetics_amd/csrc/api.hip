@@ -895,25 +895,40 @@ extern "C" size_t cp_global_negatives_scratch_floats(int64_t n_all_windows) {
     return n_all_windows > 0 ? (size_t)n_all_windows + (size_t)2 * kHeadBlocksMax * GNEG_PART : 0;
 }
 
-extern "C" int cp_global_negatives(const cp_params* p, const float* z_all, int64_t n_all_windows, const int64_t* labels,
-                                   float* scratch, float* gh_out, void* stream) {
-    if (!p || !p->easy_w || !p->easy_b || !z_all || !labels || !scratch || !gh_out || n_all_windows <= 0 ||
-        n_all_windows % CP_TASKS != 0)
-        return fail(CP_ERR_ARG, "cp_global_negatives args");
+// one workgroup per CU: each wave ends with 41 cross-lane sums, so several windows per thread beat more workgroups
+// (tools/gneg_bench.py, 1 / 8 ranks' rows: 37 / 123 us with 256 workgroups, 59 / 153 with up to 1024)
+extern "C" int cp_global_negatives_g(const cp_params* p, const float* z, int64_t n_windows, const int64_t* labels, float* scratch,
+                                     float* gh, void* stream) {
+    if (!p || !p->easy_w || !p->easy_b || !z || !labels || !scratch || !gh || n_windows <= 0 || n_windows % CP_TASKS != 0)
+        return fail(CP_ERR_ARG, "cp_global_negatives_g args");
     hipStream_t st = (hipStream_t)stream;
     float* pos = scratch;
-    float* part = scratch + n_all_windows;
-    // one workgroup per CU: each wave ends with 41 cross-lane sums, so several windows per thread beat more workgroups
-    // (tools/gneg_bench.py, 1 / 8 ranks' rows: 37 / 123 us with 256 workgroups, 59 / 153 with up to 1024)
-    const int blocks = grid_rows(n_all_windows, 256, 256);
+    float* part = scratch + n_windows;
+    const int blocks = grid_rows(n_windows, 256, 256);
     ProfScope ps(CP_K_HEAD, st);
-    hipLaunchKernelGGL(gneg_g_kernel, dim3(blocks), dim3(256), 0, st, z_all, n_all_windows, p->easy_w, p->easy_b, labels, part, pos);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(GNEG_PART)), dim3(FIN_THREADS), 0, st, part, blocks, GNEG_PART, gh_out);
-    float* part2 = part + (size_t)kHeadBlocksMax * GNEG_PART;
-    hipLaunchKernelGGL(gneg_h_kernel, dim3(blocks), dim3(256), 0, st, pos, n_all_windows, gh_out, labels, part2);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(GNEG_PART)), dim3(FIN_THREADS), 0, st, part2, blocks, GNEG_PART, gh_out + GNEG_PART);
-    CKL("gneg kernels");
+    hipLaunchKernelGGL(gneg_g_kernel, dim3(blocks), dim3(256), 0, st, z, n_windows, p->easy_w, p->easy_b, labels, part, pos);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(GNEG_PART)), dim3(FIN_THREADS), 0, st, part, blocks, GNEG_PART, gh);
+    CKL("gneg_g kernels");
     return 0;
+}
+
+extern "C" int cp_global_negatives_h(int64_t n_windows, const int64_t* labels, float* scratch, float* gh, void* stream) {
+    if (!labels || !scratch || !gh || n_windows <= 0 || n_windows % CP_TASKS != 0) return fail(CP_ERR_ARG, "cp_global_negatives_h args");
+    hipStream_t st = (hipStream_t)stream;
+    const float* pos = scratch;
+    float* part2 = scratch + n_windows + (size_t)kHeadBlocksMax * GNEG_PART;
+    const int blocks = grid_rows(n_windows, 256, 256);
+    ProfScope ps(CP_K_HEAD, st);
+    hipLaunchKernelGGL(gneg_h_kernel, dim3(blocks), dim3(256), 0, st, pos, n_windows, gh, labels, part2);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(GNEG_PART)), dim3(FIN_THREADS), 0, st, part2, blocks, GNEG_PART, gh + GNEG_PART);
+    CKL("gneg_h kernels");
+    return 0;
+}
+
+extern "C" int cp_global_negatives(const cp_params* p, const float* z_all, int64_t n_all_windows, const int64_t* labels,
+                                   float* scratch, float* gh_out, void* stream) {
+    if (int e = cp_global_negatives_g(p, z_all, n_all_windows, labels, scratch, gh_out, stream)) return e;
+    return cp_global_negatives_h(n_all_windows, labels, scratch, gh_out, stream);
 }
 
 static int head_impl(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels, int64_t n_groups,

@@ -335,18 +335,30 @@ class Engine:
                                              self._stream()), "cp_head_gneg")
         return out, pred, logits
 
-    def global_negatives(self, z_all: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-        """cp_global_negatives: z_all (n_all,16) f32 = the z rows of the GLOBAL batch (dist.all_gather_rows of every rank's
-        encoder output; one rank: its own z) -> the (2,64) table {G, H} that head(..., gneg=) takes."""
+    def global_negatives(self, z_all: torch.Tensor, labels: torch.Tensor, all_reduce=None) -> torch.Tensor:
+        """The (2,64) table {G, H} that head(..., gneg=) takes.
+        all_reduce=None (cp_global_negatives): z_all (n_all,16) f32 = the z rows of the GLOBAL batch (dist.all_gather_rows of every
+        rank's encoder output; one rank: its own z).
+        all_reduce=fn (cp_global_negatives_g / _h): z_all = THIS rank's rows only; fn(t) sums a 64-float device tensor over the ranks
+        in place on the current stream (torch.distributed.all_reduce).  The class table is replicated, so G and H are sums of
+        per-rank terms: two 256-byte collectives instead of the all-gather of z, same table."""
         assert z_all.dtype == torch.float32 and z_all.is_contiguous() and z_all.shape[1] == CP_D_E
         n_all = z_all.shape[0]
         need = self.lib.cp_global_negatives_scratch_floats(n_all)
         if getattr(self, "_gneg_scratch", None) is None or self._gneg_scratch.numel() < need:
             self._gneg_scratch = torch.empty(need, dtype=torch.float32, device=self.device)
         gh = torch.empty(2, 64, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.cp_global_negatives(C.byref(self._p), z_all.data_ptr(), n_all, labels.data_ptr(),
-                                                self._gneg_scratch.data_ptr(), gh.data_ptr(), self._stream()),
-                   "cp_global_negatives")
+        if all_reduce is None:
+            _lib.check(self.lib.cp_global_negatives(C.byref(self._p), z_all.data_ptr(), n_all, labels.data_ptr(),
+                                                    self._gneg_scratch.data_ptr(), gh.data_ptr(), self._stream()),
+                       "cp_global_negatives")
+            return gh
+        _lib.check(self.lib.cp_global_negatives_g(C.byref(self._p), z_all.data_ptr(), n_all, labels.data_ptr(),
+                                                  self._gneg_scratch.data_ptr(), gh.data_ptr(), self._stream()), "cp_global_negatives_g")
+        all_reduce(gh[0])
+        _lib.check(self.lib.cp_global_negatives_h(n_all, labels.data_ptr(), self._gneg_scratch.data_ptr(), gh.data_ptr(), self._stream()),
+                   "cp_global_negatives_h")
+        all_reduce(gh[1])
         return gh
 
     # ------------------------------------------------------------------ synchronised BatchNorm (SURVEY 8e)

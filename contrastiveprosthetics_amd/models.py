@@ -114,8 +114,9 @@ class Model(nn.Module):
         pass seed + rank there so that their shards do not share one mask (parameters are broadcast anyway).
         global_negatives / sync_bn (additive, SURVEY 8e, both off by default = the reference's semantics at the local
         batch): training batches take the class->EMG direction of the loss over the z embeddings of the GLOBAL batch
-        (one RCCL all-gather per step; cp_global_negatives / cp_head_gneg) / every BatchNorm of the sEMG encoder uses the
-        statistics of the global batch (cp_set_stats_allreduce)."""
+        (global_negatives=True or "gather": one RCCL all-gather of z per step, cp_global_negatives / cp_head_gneg;
+        "reduce": the same table from per-rank partial sums and two 64-float all-reduces, cp_global_negatives_g / _h, no z
+        moves) / every BatchNorm of the sEMG encoder uses the statistics of the global batch (cp_set_stats_allreduce)."""
         super().__init__()
         if prediction or glove:
             raise NotImplementedError("only the contrastive mode (prediction=False, glove=False) is accelerated; "
@@ -132,6 +133,9 @@ class Model(nn.Module):
                              class_encoder=class_encoder)
         self.engine.init_parameters(seed)
         self.global_negatives = bool(global_negatives)
+        self.global_negatives_mode = global_negatives if isinstance(global_negatives, str) else "gather"
+        if self.global_negatives_mode not in ("gather", "reduce"):
+            raise ValueError("global_negatives: False, True, 'gather' or 'reduce'")
         self.sync_bn = bool(sync_bn)
         if self.global_negatives and class_encoder != "onehot":
             raise NotImplementedError("global negatives need the shared one-hot class table")
@@ -215,7 +219,10 @@ class Model(nn.Module):
             if self.global_negatives and self.training and V == 1:
                 # the global-batch z matrix: every rank's rows, rank-major (world 1: this rank's own z, no collective)
                 from . import dist as cpdist
-                gh = self.engine.global_negatives(cpdist.all_gather_rows(z), labels)
+                if self.global_negatives_mode == "reduce":
+                    gh = self.engine.global_negatives(z, labels, all_reduce=cpdist.all_reduce_sum_)
+                else:
+                    gh = self.engine.global_negatives(cpdist.all_gather_rows(z), labels)
             out, pred, logits = self.engine.head(z, labels, V, want_grad=want_grad, want_logits=True, gneg=gh)
         self._pending = dict(x=x, out=out, pred=pred, labels=labels, B=B, V=V, T=T, want_grad=want_grad, done=False)
         self._last_logits = logits

@@ -85,7 +85,8 @@ def train_loop(dataset, params, checkpoint=False, checkpoint_dir="../checkpoints
     # per rank so that the shards of one global batch do not share a mask
     model = Model(params=params, train_model=True, adabn=args.no_adabn, prediction=args.prediction, glove=args.glove,
                   device="cuda", dtype=args.dtype, class_encoder=getattr(args, "class_encoder", "onehot"),
-                  dropout_seed=42 + rank, global_negatives=bool(getattr(args, "global_negatives", False)) and not solo,
+                  dropout_seed=42 + rank,
+                  global_negatives=(getattr(args, "global_negatives_mode", "gather") if getattr(args, "global_negatives", False) and not solo else False),
                   sync_bn=bool(getattr(args, "sync_bn", False)) and not solo).to(torch.float32)
     if load is not None:
         print("Loading model")
@@ -280,6 +281,9 @@ def build_parser():
     parser.add_argument("--global_negatives", action="store_true",
                         help="extension: the class->EMG direction of the training loss ranges over the z embeddings of the GLOBAL "
                              "batch (one all-gather per step under data parallelism); off = the reference's per-group loss")
+    parser.add_argument("--global_negatives_mode", default="gather", choices=["gather", "reduce"],
+                        help="gather: the all-gather of z (BASELINE config 2); reduce: the same {G, H} table from per-rank partial sums "
+                             "and two 64-float all-reduces (the class table is replicated: no z has to move)")
     parser.add_argument("--sync_bn", action="store_true",
                         help="extension: BatchNorm statistics over the global batch under data parallelism (18 small all-reduces "
                              "per step); off = every rank uses its shard's statistics, the reference at B_local")

@@ -163,6 +163,14 @@ int cp_global_negatives(const cp_params* p, const float* z_all, int64_t n_all_wi
 int cp_head_gneg(const cp_config* cfg, const cp_params* p, const float* z, const int64_t* labels,
                  int64_t n_groups, int32_t V, int32_t want_grad, void* ws, size_t ws_bytes,
                  float* loss_correct, int32_t* pred, float* logits, cp_params* grads, const float* gh, void* stream);
+/* The same table WITHOUT moving z: the class table is replicated, so G and H are sums of per-rank terms and only two 41-float
+ * vectors have to cross ranks.  cp_global_negatives_g: this rank's rows' part of G into gh[0..63]; the caller sums gh[0..63] over
+ * the ranks (one all-reduce of 64 floats); cp_global_negatives_h: with the summed G in place, this rank's groups' part of H into
+ * gh[64..127]; the caller sums that too.  scratch as above for n_local_windows, kept between the two calls (it holds the positives).
+ * cp_global_negatives on the gathered rows == _g, sum, _h, sum on each rank's own rows (tests/test_gpu_global_batch.py). */
+int cp_global_negatives_g(const cp_params* p, const float* z_local, int64_t n_local_windows, const int64_t* labels,
+                          float* scratch, float* gh, void* stream);
+int cp_global_negatives_h(int64_t n_local_windows, const int64_t* labels, float* scratch, float* gh, void* stream);
 
 /* ---- synchronised BatchNorm (opt-in, default off = every rank normalises with its own shard's statistics,
  * which is the reference at B_local, code/models.py:17-35,238-243) ----------------------------------------------------

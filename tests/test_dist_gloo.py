@@ -152,6 +152,25 @@ def _gneg_worker(rank, world, port, out_dir):
     gathered = cpdist.all_gather_rows(z_local)                          # the collective under test
     assert torch.equal(gathered, z_all_true)
     loss, dz, dE = _gneg_local_terms(z_local, gathered, E, labels, world)
+    # the same table without moving z (cp_global_negatives_g / _h, engine.global_negatives(all_reduce=...)): the class table is
+    # replicated, so G and H are sums of per-rank terms -- two all-reduces of 41 numbers
+    lab = labels[:T]
+    En = E / E.norm(dim=-1, keepdim=True)
+    neg = (lab.reshape(T, 1) != torch.arange(T).reshape(1, T)).double()
+    pos_of_class = torch.empty(T, dtype=torch.long)
+    pos_of_class[lab] = torch.arange(T)
+
+    def table(rows, G=None):
+        S = ((rows / rows.norm(dim=-1, keepdim=True)) @ En.t()).reshape(-1, T, T)
+        if G is None:
+            return (S.exp() * neg).sum((0, 1))
+        return (1.0 / (S[:, pos_of_class, torch.arange(T)].exp() + G)).sum(0)
+    G_red = table(z_local)
+    cpdist.all_reduce_sum_(G_red)
+    H_red = table(z_local, G_red)
+    cpdist.all_reduce_sum_(H_red)
+    np.testing.assert_allclose(G_red.numpy(), table(gathered).numpy(), rtol=1e-12)
+    np.testing.assert_allclose(H_red.numpy(), table(gathered, table(gathered)).numpy(), rtol=1e-12)
     # single-process definition on the concatenated batch (oracle, autograd)
     za = z_all_true.clone().requires_grad_(True)
     Ea = E.clone().requires_grad_(True)

@@ -60,6 +60,57 @@ def test_global_negatives_head_matches_oracle(adabn):
     assert abs(out[0].item() - m.loss_vectorized(ref_logits.detach(), label).item()) > 1e-3
 
 
+def test_global_negatives_by_partial_sums_equals_gathered_rows():
+    """cp_global_negatives_g / _h on each "rank's" rows with the two 64-float sums done by hand == cp_global_negatives on the
+    concatenated rows (what the all-gather delivers): the class table is replicated, so no z has to move.  Three uneven shards of
+    1,000 groups; the table entries are sums of exponentials grouped differently: 2e-6 relative."""
+    from contrastiveprosthetics_amd.engine import Engine
+    e = Engine(adabn=False, dtype="f32", dp_emg=0.0, device="cuda")
+    e.init_parameters(3)
+    G_all = 1000
+    z = (0.7 * randn(5, (G_all * T, 16))).cuda()
+    labels = torch.arange(T).repeat(G_all).cuda()
+    want = e.global_negatives(z, labels).clone()
+    cuts = [0, 130, 640, G_all]
+    shards = [z[cuts[i] * T:cuts[i + 1] * T].contiguous() for i in range(3)]
+    engines = []
+    for sh in shards:                                          # one engine (its own scratch: the positives live there) per "rank"
+        r = Engine(adabn=False, dtype="f32", dp_emg=0.0, device="cuda")
+        r.init_parameters(3)
+        engines.append(r)
+    # the all-reduce, by hand: phase 1 collects every rank's G part, phase 2 every rank's H part
+    parts = []
+    tables = []
+
+    class Stop(Exception):
+        pass
+
+    def collect(t):
+        parts.append(t.clone())
+        raise Stop
+    for r, sh in zip(engines, shards):
+        try:
+            r.global_negatives(sh, labels, all_reduce=collect)
+        except Stop:
+            pass
+    G_sum = torch.stack(parts).sum(0)
+    np.testing.assert_allclose(G_sum.cpu().numpy()[:T], want[0].cpu().numpy()[:T], rtol=2e-6)
+    h_parts = []
+    for r, sh in zip(engines, shards):
+        calls = []
+
+        def fn(t, calls=calls):
+            if not calls:
+                t.copy_(G_sum)                                 # the summed G
+            else:
+                h_parts.append(t.clone())
+            calls.append(1)
+        tables.append(r.global_negatives(sh, labels, all_reduce=fn))
+    H_sum = torch.stack(h_parts).sum(0)
+    np.testing.assert_allclose(H_sum.cpu().numpy()[:T], want[1].cpu().numpy()[:T], rtol=2e-6)
+    assert float(G_sum[T:].abs().max()) == 0.0 and float(H_sum[T:].abs().max()) == 0.0
+
+
 def test_model_flag_global_negatives_trains():
     from contrastiveprosthetics_amd.models import Model
     m = Model(dict(BEST), adabn=False, device="cuda", dtype="bf16", global_negatives=True).to(torch.float32)
