@@ -179,11 +179,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmNTAr
     // closing wait + barrier, wave 0 of block 0, into the unused tail of the partial-row buffer
     unsigned long long* stamps = (unsigned long long*)(a.partials + (size_t)200 * 2 * a.F);
     auto stamp = [&](int slot) {
-        unsigned long long t;
+        unsigned long long t, rt;
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(rt) :: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (blockIdx.x == 0 && tid == 0) stamps[slot] = t;
+        // shader-clock cycles and the 100 MHz real-time counter side by side: their ratio is the clock the SIMD ran at
+        if (blockIdx.x == 0 && tid == 0) { stamps[2 * slot] = t; stamps[2 * slot + 1] = rt; }
     };
 #else
     auto stamp = [&](int) {};

@@ -14,6 +14,8 @@ done
 timeout -k 10 280 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/${R}_SQ -- python3 bench.py --main_only --steps 4 --warmup 2 "$@" > $O/${R}_SQ.log 2>&1 || echo "SQ pass failed (see $O/${R}_SQ.log)"
 python tools/parse_profile.py stats $O/${R}_stats $O/${R}_kernel_stats.csv
 python tools/step_kernels.py $O/${R}_stats > $O/${R}_step_kernels.txt
+python tools/step_kernels.py $O/${R}_stats --timeline > $O/${R}_step_timeline.txt
+python tools/step_kernels.py $O/${R}_stats --by_position gemm_tn > $O/${R}_wgrad_by_position.txt
 python tools/parse_profile.py traffic $O/${R}_FETCH_SIZE $O/${R}_WRITE_SIZE $O/${R}_traffic.json
 python tools/parse_profile.py mfma $O/${R}_SQ $O/${R}_mfma.json || true
 # the raw traces stay on the box: gpurun merges at most 64 MiB back

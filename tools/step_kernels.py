@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel totals of ONE training step from a rocprofv3 --kernel-trace run of bench.py (rocpd SQLite):
-   python tools/step_kernels.py <dir with *_results.db> [--timeline]"""
+   python tools/step_kernels.py <dir with *_results.db> [--timeline]
+   python tools/step_kernels.py <dir> --by_position <kernel name part>    (the i-th launch of that kernel in every traced step: min / avg / max)"""
 import collections
 import glob
 import os
@@ -16,6 +17,17 @@ else:
     db = glob.glob(os.path.join(sys.argv[1], "**", "*_results.db"), recursive=True)[0]
     rows = list(sqlite3.connect(db).execute("select name, start, end, duration from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if r[0].startswith("gather_groups")]
+if "--by_position" in sys.argv:
+    pat = sys.argv[sys.argv.index("--by_position") + 1]
+    per = collections.defaultdict(list)
+    for a, b in zip(idx[:-1], idx[1:]):
+        for i, r in enumerate([r for r in rows[a:b] if pat in r[0]]):
+            per[i].append(r[3] / 1e3)
+    print("%s: launch position within a step, over %d traced steps (us)" % (pat, len(idx) - 1))
+    for i in sorted(per):
+        v = per[i]
+        print("  #%d: min %6.1f  avg %6.1f  max %6.1f   (%d samples)" % (i, min(v), sum(v) / len(v), max(v), len(v)))
+    sys.exit(0)
 a, b = idx[-2], idx[-1]
 tot = collections.defaultdict(lambda: [0, 0.0])
 for r in rows[a:b]:

@@ -72,16 +72,25 @@ def timed(dbg, iters=20):
 
 
 if os.environ.get("WS_STAMP"):
+    # a -DCP_VARIANTS -DWS_STAMP build (tools/ws_stamps.sh): the 32x32x16 form (dbg 512) carries the stamps
     partials.zero_()
-    lib.cp_debug_gemm(1, 0, M, K, F, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), 0, partials.data_ptr(), 0, st)
+    lib.cp_debug_gemm(1, 0, M, K, F, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), 0, partials.data_ptr(), 512, st)
     torch.cuda.synchronize()
-    stv = partials[200 * 2 * F: 200 * 2 * F + 2 * 3 * 24].view(torch.int64).cpu().tolist()
-    nt = sum(1 for i in range(24) if stv[3 * i])
-    print("in-kernel stamps, block 0 wave 0 (cycles): tile: k loop | closing wait + barrier | gap to next tile")
+    stv = partials[200 * 2 * F: 200 * 2 * F + 2 * 2 * 3 * 24].view(torch.int64).cpu().tolist()
+    cyc, rt = stv[0::2], stv[1::2]
+    nt = sum(1 for i in range(24) if cyc[3 * i])
+    print("in-kernel stamps, block 0 wave 0: tile: k loop cycles (us, GHz) | closing wait + barrier cycles | gap to the next tile")
     for i in range(nt):
-        nxt = stv[3 * i + 3] - stv[3 * i + 2] if i + 1 < nt else 0
-        print("  tile %2d: %6d | %6d | %6d" % (i, stv[3 * i + 1] - stv[3 * i], stv[3 * i + 2] - stv[3 * i + 1], nxt))
-    print("  whole: %d cycles from the first stamp to the last" % (stv[3 * nt - 1] - stv[0]))
+        nxt = cyc[3 * i + 3] - cyc[3 * i + 2] if i + 1 < nt else 0
+        kc, kus = cyc[3 * i + 1] - cyc[3 * i], (rt[3 * i + 1] - rt[3 * i]) / 100.0
+        print("  tile %2d: %6d (%5.2f us, %4.2f GHz) | %6d | %6d" % (i, kc, kus, kc / kus / 1e3 if kus > 0 else 0.0, cyc[3 * i + 2] - cyc[3 * i + 1], nxt))
+    tc, tus = cyc[3 * nt - 1] - cyc[0], (rt[3 * nt - 1] - rt[0]) / 100.0
+    print("  whole: %d cycles in %.2f us from the first stamp to the last = %.2f GHz" % (tc, tus, tc / tus / 1e3))
+    for _ in range(2):
+        timed(512, 5)
+    v = sorted(timed(512) for _ in range(6))
+    print("  launch (32x32x16 form, this build): median %.1f us  min %.1f  max %.1f" % (v[3], v[0], v[-1]))
+    sys.exit(0)
 for _ in range(2):
     timed(0, 5), timed(512, 5), timed(256, 5)
 res = {0: [], 512: [], 256: []}
