@@ -119,39 +119,43 @@ __device__ __forceinline__ uint4 sm_bn_drop_chunk(const uint4& in, const float* 
 }
 
 // ---- the two main loops, latency first ----------------------------------------------------------------------------------------
-// With 44-170 workgroups on 256 CUs there is ONE workgroup per CU and nothing to overlap its memory latency with, so a loop step must
-// have as many loads in flight as fit: a step moves SM_NSUB sub-tiles of BK (16-bit: 2 x 64 k) per operand, and the loads of step
-// i + 2 are issued before the MFMAs of step i (two register sets, two LDS buffers).  (The first version -- one 64-deep sub-tile per
-// step, loads one step ahead, the statistics prologue reading one partial row per round trip -- took 21 us per layer at 328 rows.)
-#define SM_NSUB 2
+// With 44-170 workgroups on 256 CUs there is ONE workgroup per CU and nothing to overlap its memory latency with, so the loops keep as
+// many loads in flight as the registers hold: a step moves NSUB sub-tiles of BK per operand (16-bit: 4 x 64 k -- a K = 512 contraction is
+// TWO steps, both issued before anything else happens in the kernel; f32: 2 x 32 k), into one of two register sets; the loads of step
+// i + 2 are issued as soon as step i's registers have gone to LDS.  `mid()` runs between the first two steps' loads and their first use:
+// the kernels pass their statistics prologue (a round trip of its own, and a barrier) there, so it hides under the operand fetch.
+// One LDS stage: store, barrier, MFMAs, barrier -- with every load already in flight the second buffer bought nothing.
+// History (tools/small_stamps.py, k loop of one fc forward launch at 328 rows, bf16): one 64-deep sub-tile per step, loads one step
+// ahead, 21 us per layer; two sub-tiles, loads two steps ahead but TRANSFORMED in the load phase (every step waited for the load it had
+// just issued) 6.5 us; raw loads, transforms at store time 4.6 us; this form: see DESIGN.md 7g.
+template <typename T> struct SmNsub { static constexpr int v = sizeof(T) == 2 ? 4 : 2; };
 // NT: acc += A'[32 rows][K] x W[BN rows][K]^T for the wave's 32 x 32 piece (W rows wrow .. wrow+31).  loadA(sub) / loadW(sub, i) return the
-// thread's 16-byte chunk (row tid >> 3 [+ 32 i], chunk tid & 7) of sub-tile `sub`.
-template <typename T, int BN, typename RawA, typename FA, typename XA, typename FW>
-__device__ __forceinline__ void sm_nt_loop(f32x16& acc, unsigned char* smem, int nsub, FA&& loadA, XA&& xformA, FW&& loadW, int wrow, bool do_mma) {
-    constexpr int A_BYTES = SM_BM * 128, W_BYTES = BN * 128, SUB = A_BYTES + W_BYTES, STAGE = SM_NSUB * SUB, W_IT = BN / 32;
+// thread's 16-byte chunk (row tid >> 3 [+ 32 i], chunk tid & 7) of sub-tile `sub`; xformA(raw, sub) turns the raw A chunk into the operand.
+template <typename T, int BN, typename RawA, typename FA, typename XA, typename FW, typename Mid>
+__device__ __forceinline__ void sm_nt_loop(f32x16& acc, unsigned char* smem, int nsub, FA&& loadA, XA&& xformA, FW&& loadW, int wrow, bool do_mma,
+                                           Mid&& mid, long long* dbg = nullptr) {
+    constexpr int NSUB = SmNsub<T>::v;
+    constexpr int A_BYTES = SM_BM * 128, W_BYTES = BN * 128, SUB = A_BYTES + W_BYTES, W_IT = BN / 32;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, sc = tid & 7, sr = tid >> 3;
-    const int nit = (nsub + SM_NSUB - 1) / SM_NSUB;
-    // A step's loads only ISSUE (raw registers); the A operand's transform (BatchNorm affine + dropout, or BatchNorm + ReLU backward) runs
-    // when the step is stored to LDS, two steps later, when the data has long arrived.  (Transforming in the load phase made every step
-    // wait for the load it had just issued: 1.6 us per step = one full round trip, tools/small_stamps.py.)
-    RawA ar[2][SM_NSUB];
-    uint4 wr[2][SM_NSUB][W_IT];
+    const int nit = (nsub + NSUB - 1) / NSUB;
+    RawA ar[2][NSUB];
+    uint4 wr[2][NSUB][W_IT];
     auto load = [&](int it, int set) {
 #pragma unroll
-        for (int u = 0; u < SM_NSUB; ++u) {
-            const int sub = it * SM_NSUB + u;
-            const int subc = sub < nsub ? sub : nsub - 1;       // (a contraction shorter than a step: loaded twice, the second copy zeroed below)
+        for (int u = 0; u < NSUB; ++u) {
+            const int sub = it * NSUB + u;
+            const int subc = sub < nsub ? sub : nsub - 1;       // (a contraction shorter than a step: loaded again, zeroed below)
 #pragma unroll
             for (int i = 0; i < W_IT; ++i) wr[set][u][i] = loadW(subc, i);
             ar[set][u] = loadA(subc);
         }
     };
-    auto store = [&](int it, int set, int buf) {
+    auto store = [&](int it, int set) {
 #pragma unroll
-        for (int u = 0; u < SM_NSUB; ++u) {
-            const int sub = it * SM_NSUB + u;
+        for (int u = 0; u < NSUB; ++u) {
+            const int sub = it * NSUB + u;
             const bool ok = sub < nsub;
-            unsigned char* As = smem + buf * STAGE + u * SUB;
+            unsigned char* As = smem + u * SUB;
             unsigned char* Ws = As + A_BYTES;
             const uint4 av = xformA(ar[set][u], ok ? sub : nsub - 1);
             *(uint4*)(As + lds_tile_off(sr, sc)) = ok ? av : make_uint4(0, 0, 0, 0);
@@ -159,11 +163,11 @@ __device__ __forceinline__ void sm_nt_loop(f32x16& acc, unsigned char* smem, int
             for (int i = 0; i < W_IT; ++i) *(uint4*)(Ws + lds_tile_off(sr + 32 * i, sc)) = ok ? wr[set][u][i] : make_uint4(0, 0, 0, 0);
         }
     };
-    auto compute = [&](int buf) {
+    auto compute = [&]() {
         if (!do_mma) return;
 #pragma unroll
-        for (int u = 0; u < SM_NSUB; ++u) {
-            const unsigned char* As = smem + buf * STAGE + u * SUB;
+        for (int u = 0; u < NSUB; ++u) {
+            const unsigned char* As = smem + u * SUB;
             const unsigned char* Ws = As + A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -173,45 +177,67 @@ __device__ __forceinline__ void sm_nt_loop(f32x16& acc, unsigned char* smem, int
             }
         }
     };
+#ifdef SM_STAMP
+    auto lstamp = [&](int slot) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[slot] = (long long)__builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#else
+    auto lstamp = [&](int) {};
+#endif
     load(0, 0);
     if (nit > 1) load(1, 1);
-    store(0, 0, 0);
-    __syncthreads();
+    lstamp(0);
+    mid();
+    lstamp(1);
     for (int it = 0; it < nit; it += 2) {
+        store(it, 0);
+        lstamp(2 + 4 * it);
+        __syncthreads();
         if (it + 2 < nit) load(it + 2, 0);
-        compute(0);
-        if (it + 1 < nit) store(it + 1, 1, 1);
+        lstamp(3 + 4 * it);
+        compute();
+        lstamp(4 + 4 * it);
         __syncthreads();
+        lstamp(5 + 4 * it);
         if (it + 1 >= nit) break;
-        if (it + 3 < nit) load(it + 3, 1);
-        compute(1);
-        if (it + 2 < nit) store(it + 2, 0, 0);
+        store(it + 1, 1);
+        lstamp(6 + 4 * it);
         __syncthreads();
+        if (it + 3 < nit) load(it + 3, 1);
+        lstamp(7 + 4 * it);
+        compute();
+        lstamp(8 + 4 * it);
+        __syncthreads();
+        lstamp(9 + 4 * it);
     }
 }
 template <typename T, int BN> struct SmNT {
-    static constexpr int LOOP_BYTES = 2 * SM_NSUB * (SM_BM * 128 + BN * 128);
+    static constexpr int LOOP_BYTES = SmNsub<T>::v * (SM_BM * 128 + BN * 128);
     static constexpr int C_PITCH = BN * (int)sizeof(T) + 16, C_BYTES = SM_BM * C_PITCH, RED_BYTES = 2 * 256 * DT<T>::EPC * 4;
     static constexpr int BYTES = LOOP_BYTES > C_BYTES + RED_BYTES ? LOOP_BYTES : C_BYTES + RED_BYTES;
 };
 
 // TN: acc += X'[rows][64 cols]^T x Y'[rows][64 cols] over the rows m_begin .. m_end of both operands (sub-steps of 32 rows), for the wave's
-// 32 x 32 piece (X columns wp*32.., Y columns wq*32..).  loadX(m, ch) / loadY(m, ch): the 16-byte chunk ch of row m (zero past m_end).
-template <typename T, typename RawX, typename FX, typename XX, typename FY, typename XY>
+// 32 x 32 piece (X columns wp*32.., Y columns wq*32..).  loadX(m, ch) / loadY(m, ch): the raw 16-byte chunk ch of row m;
+// xformX(raw, m, ch, ok) / xformY(raw, m, ch): the operands.
+template <typename T, typename RawX, typename FX, typename XX, typename FY, typename XY, typename Mid>
 __device__ __forceinline__ void sm_tn_loop(f32x16& acc, unsigned char* smem, int64_t m_begin, int64_t m_end, FX&& loadX, XX&& xformX, FY&& loadY,
-                                           XY&& xformY, int wp, int wq) {
+                                           XY&& xformY, int wp, int wq, Mid&& mid) {
     using D = DT<T>;
+    constexpr int NSUB = SmNsub<T>::v;
     constexpr int EPC = D::EPC, KSTEP = D::KSTEP, CPRX = 64 / EPC, RS = 256 / CPRX, IT = 32 / RS;
-    constexpr int PX = TNPitch<T, 64>::value, XB = 32 * PX, SUB = 2 * XB, STAGE = SM_NSUB * SUB;
+    constexpr int PX = TNPitch<T, 64>::value, XB = 32 * PX, SUB = 2 * XB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int rs = tid / CPRX, ch = tid % CPRX;
-    const int nit = (int)((m_end - m_begin + 32 * SM_NSUB - 1) / (32 * SM_NSUB));
-    RawX xr[2][SM_NSUB][IT];
-    uint4 yr[2][SM_NSUB][IT];
-    auto row_of = [&](int it, int u, int q) -> int64_t { return m_begin + ((int64_t)it * SM_NSUB + u) * 32 + rs + RS * q; };
+    const int nit = (int)((m_end - m_begin + 32 * NSUB - 1) / (32 * NSUB));
+    RawX xr[2][NSUB][IT];
+    uint4 yr[2][NSUB][IT];
+    auto row_of = [&](int it, int u, int q) -> int64_t { return m_begin + ((int64_t)it * NSUB + u) * 32 + rs + RS * q; };
     auto load = [&](int it, int set) {              // (raw loads only, rows clamped: the transforms run at store time, see sm_nt_loop)
 #pragma unroll
-        for (int u = 0; u < SM_NSUB; ++u)
+        for (int u = 0; u < NSUB; ++u)
 #pragma unroll
             for (int q = 0; q < IT; ++q) {
                 const int64_t m = row_of(it, u, q);
@@ -220,10 +246,10 @@ __device__ __forceinline__ void sm_tn_loop(f32x16& acc, unsigned char* smem, int
                 yr[set][u][q] = loadY(mc, ch);
             }
     };
-    auto store = [&](int it, int set, int buf) {
+    auto store = [&](int it, int set) {
 #pragma unroll
-        for (int u = 0; u < SM_NSUB; ++u) {
-            unsigned char* Xs = smem + buf * STAGE + u * SUB;
+        for (int u = 0; u < NSUB; ++u) {
+            unsigned char* Xs = smem + u * SUB;
             unsigned char* Ys = Xs + XB;
 #pragma unroll
             for (int q = 0; q < IT; ++q) {
@@ -236,10 +262,10 @@ __device__ __forceinline__ void sm_tn_loop(f32x16& acc, unsigned char* smem, int
             }
         }
     };
-    auto compute = [&](int buf) {
+    auto compute = [&]() {
 #pragma unroll
-        for (int u = 0; u < SM_NSUB; ++u) {
-            const unsigned char* Xs = smem + buf * STAGE + u * SUB;
+        for (int u = 0; u < NSUB; ++u) {
+            const unsigned char* Xs = smem + u * SUB;
             const unsigned char* Ys = Xs + XB;
 #pragma unroll
             for (int ks = 0; ks < 32 / KSTEP; ++ks) {
@@ -255,25 +281,25 @@ __device__ __forceinline__ void sm_tn_loop(f32x16& acc, unsigned char* smem, int
             }
         }
     };
-    if (nit <= 0) return;
-    load(0, 0);
+    if (nit > 0) load(0, 0);
     if (nit > 1) load(1, 1);
-    store(0, 0, 0);
-    __syncthreads();
+    mid();
     for (int it = 0; it < nit; it += 2) {
+        store(it, 0);
+        __syncthreads();
         if (it + 2 < nit) load(it + 2, 0);
-        compute(0);
-        if (it + 1 < nit) store(it + 1, 1, 1);
+        compute();
         __syncthreads();
         if (it + 1 >= nit) break;
+        store(it + 1, 1);
+        __syncthreads();
         if (it + 3 < nit) load(it + 3, 1);
-        compute(1);
-        if (it + 2 < nit) store(it + 2, 0, 0);
+        compute();
         __syncthreads();
     }
 }
 template <typename T> struct SmTN {
-    static constexpr int BYTES = 2 * SM_NSUB * 2 * 32 * TNPitch<T, 64>::value;
+    static constexpr int BYTES = SmNsub<T>::v * 2 * 32 * TNPitch<T, 64>::value;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -364,8 +390,6 @@ __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
     auto stamp = [&](int) {};
 #endif
     stamp(0);
-    sm_finalize_stats<256>(a.bn_in, s_in, t_in, blockIdx.x == 0);
-    stamp(1);
     const uint32_t key = a.dp_thresh != 0 ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
 
     const T* __restrict__ Ag = (const T*)a.A;
@@ -384,7 +408,15 @@ __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
             return m_st < a.N ? v : make_uint4(0, 0, 0, 0);
         },
         [&](int sub, int i) -> uint4 { return *(const uint4*)(Wg + (int64_t)(f0 + sr + 32 * i) * a.K + sub * BK + sc * EPC); },
-        MODE == 0 ? wave * 32 : 0, MODE == 0 || wave == 0);
+        MODE == 0 ? wave * 32 : 0, MODE == 0 || wave == 0,
+        [&]() {                                           // (under the first two steps' loads)
+            sm_finalize_stats<256>(a.bn_in, s_in, t_in, blockIdx.x == 0);
+            stamp(1);
+        }
+#ifdef SM_STAMP
+        , MODE == 0 ? a.out_acc + 1110 : nullptr
+#endif
+        );
     stamp(2);
     // accumulator register g: feature (wave*32 +) (g&3) + 8*(g>>2) + 4*h of sample row r
     if constexpr (MODE == 1) {
@@ -491,21 +523,24 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    if constexpr (!PROJ) {
-        // coefficients of layer L (bn_bwd_finalize_kernel's arithmetic, the partial rows folded in a fixed order)
-        for (int c = tid; c < 512; c += 256) {
-            const double s1 = sm_acc_get(a.gsum + c, SM_GRAD_SHIFT), s2 = sm_acc_get(a.gsum + 512 + c, SM_GRAD_SHIFT);
-            const double mean = a.stats[c], invstd = a.stats[512 + c], scl = a.stats[1024 + c];
-            const double dot = (s2 - mean * s1) * invstd;
-            const double c1 = s1 / (double)a.N, c2 = dot / (double)a.N;
-            ca[c] = (float)scl;
-            cb[c] = (float)(-scl * invstd * c2);
-            cz[c] = (float)(-scl * (c1 - mean * invstd * c2));
-            if (blockIdx.x == 0) { a.dgamma[c] = (float)dot; a.dbeta[c] = (float)s1; }
+    // coefficients of layer L and the scale / shift of layer L-1: run as the loops' `mid()`, under the first operand loads
+    auto prologue = [&]() {
+        if constexpr (!PROJ) {
+            // coefficients of layer L (bn_bwd_finalize_kernel's arithmetic, the partial rows folded in a fixed order)
+            for (int c = tid; c < 512; c += 256) {
+                const double s1 = sm_acc_get(a.gsum + c, SM_GRAD_SHIFT), s2 = sm_acc_get(a.gsum + 512 + c, SM_GRAD_SHIFT);
+                const double mean = a.stats[c], invstd = a.stats[512 + c], scl = a.stats[1024 + c];
+                const double dot = (s2 - mean * s1) * invstd;
+                const double c1 = s1 / (double)a.N, c2 = dot / (double)a.N;
+                ca[c] = (float)scl;
+                cb[c] = (float)(-scl * invstd * c2);
+                cz[c] = (float)(-scl * (c1 - mean * invstd * c2));
+                if (blockIdx.x == 0) { a.dgamma[c] = (float)dot; a.dbeta[c] = (float)s1; }
+            }
         }
-    }
-    for (int c = tid; c < a.smod; c += 256) { s_p[c] = a.stats_p[2 * a.smod + c]; t_p[c] = a.stats_p[3 * a.smod + c]; }
-    __syncthreads();
+        for (int c = tid; c < a.smod; c += 256) { s_p[c] = a.stats_p[2 * a.smod + c]; t_p[c] = a.stats_p[3 * a.smod + c]; }
+        __syncthreads();
+    };
     const T* __restrict__ Gg = (const T*)a.Gin;
     const T* __restrict__ Rg = (const T*)a.R;
     const uint32_t key = a.dp_thresh != 0 ? (a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key) : 0u;
@@ -543,7 +578,7 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
                 return m_st < a.N ? v : make_uint4(0, 0, 0, 0);
             },
             [&](int sub, int i) -> uint4 { return *(const uint4*)(Wg + (int64_t)(k0o + sr + 32 * i) * KC + sub * BK + sc * EPC); },
-            wave * 32, true);
+            wave * 32, true, prologue);
         constexpr int C_PITCH = SmNT<T, BN>::C_PITCH;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -612,7 +647,7 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
             [&](const uint4& raw, int64_t m, int ch) -> uint4 {
                 return sm_bn_drop_chunk<T>(raw, s_p, t_p, q0 + ch * EPC, a.smod - 1, key, (uint32_t)m, (uint32_t)a.K, a.dp_thresh, a.dp_inv_keep);
             },
-            wp, wq);
+            wp, wq, prologue);
         // accumulator register g: row p = wp*32 + (g&3) + 8*(g>>2) + 4*h, column q = wq*32 + r
         float* dW = a.dW + (int64_t)split * a.slab_stride;
         {

@@ -23,4 +23,9 @@ for L in range(2, 9):
     st = acc[L, 1100:1104].tolist()
     if st[0] == 0:
         print("no stamps (library without -DSM_STAMP, or the offset guess is off)"); break
-    print(f"fc{L - 1}: prologue {(st[1] - st[0]) / 100:.2f} us, k loop {(st[2] - st[1]) / 100:.2f} us, epilogue {(st[3] - st[2]) / 100:.2f} us")
+    print(f"fc{L - 1}: loads issued + prologue {(st[1] - st[0]) / 100:.2f} us, k loop {(st[2] - st[1]) / 100:.2f} us, epilogue {(st[3] - st[2]) / 100:.2f} us")
+    ls = acc[L, 1110:1130].tolist()
+    if ls[0]:
+        names = ["issue", "mid", "store0", "sync", "mma0", "sync", "store1", "sync", "mma1", "sync"]
+        t0 = st[0]
+        print("      loop stamps (us from kernel start): " + "  ".join(f"{n} {(v - t0) / 100:.2f}" for n, v in zip(names, ls) if v))
