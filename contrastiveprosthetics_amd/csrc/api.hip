@@ -50,7 +50,7 @@ extern "C" int cp_version(void) { return CP_VERSION; }
 struct OptName { const char* name; int CpOptions::*field; };
 static const OptName kOptNames[] = {
     {"unfused_bn_bwd", &CpOptions::unfused_bn_bwd}, {"unpaired_wgrad", &CpOptions::unpaired_wgrad}, {"fp8_bridge", &CpOptions::fp8_bridge},
-    {"no_small", &CpOptions::no_small},
+    {"no_small", &CpOptions::no_small}, {"fp8_head_f32", &CpOptions::fp8_head_f32},
 #ifdef CP_VARIANTS
     {"no_ws", &CpOptions::no_ws}, {"no_wsk", &CpOptions::no_wsk}, {"no_wsd", &CpOptions::no_wsd}, {"no_wsd_st", &CpOptions::no_wsd_st},
     {"staged_r_epilogue", &CpOptions::staged_r_epilogue}, {"ws32", &CpOptions::ws32}, {"wsd32", &CpOptions::wsd32}, {"tn_w4", &CpOptions::tn_w4},
@@ -967,9 +967,16 @@ static int head_impl(const cp_config* cfg, const cp_params* p, const float* z, c
     a.logits = logits; a.pred = pred; a.partials = (float*)(base + w.head_part);
     a.gneg = gneg;
     const int blocks = grid_rows(n_groups, HEAD_WAVES * (n_groups >= 2048 ? 2 : 1), kHeadBlocksMax);   // (>= 2048 groups: two per wave, half the prologues)
+    // CP_FP8 (BASELINE config 4): the logits on the block-scaled 8-bit MFMA; "fp8_head_f32" keeps the f32 products (tests)
+    const bool f8l = cfg->dtype == CP_FP8 && !g_opt.fp8_head_f32;
     if (cfg->dtype != CP_F32) {
-        if (gneg) hipLaunchKernelGGL((head_kernel<bf16_t, false, true>), dim3(blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((head_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a);
+        if (f8l) {
+            if (gneg) hipLaunchKernelGGL((head_kernel<bf16_t, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((head_kernel<bf16_t, false, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        } else {
+            if (gneg) hipLaunchKernelGGL((head_kernel<bf16_t, false, true>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((head_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a);
+        }
     } else {
         if (gneg) hipLaunchKernelGGL((head_kernel<float, false, true>), dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((head_kernel<float>), dim3(blocks), dim3(256), 0, st, a);

@@ -14,7 +14,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define CP_WAVE 64
 
 // Process-wide switches of the library, set through cp_debug_set_option (include/cpnative.h) -- never read from the environment on
-// a launch path.  The product library knows three: orders of the SAME kernels that tests compare.  A tools-only build with
+// a launch path.  The product library knows five: orders / forms of the SAME computation that tests compare.  A tools-only build with
 // -DCP_VARIANTS (make -C csrc variants -> build/libcpnative_variants.so) also carries the kernels that were measured and
 // superseded, with one switch each; there $CPNATIVE_<NAME> seeds the switch once when the library is loaded (tools/ab_env.sh).
 struct CpOptions {
@@ -22,6 +22,7 @@ struct CpOptions {
     int unpaired_wgrad = 0;      // one weight-gradient launch per layer behind a dropout instead of paired launches
     int fp8_bridge = 0;          // CP_FP8: expand the saved 8-bit tensors to bf16 and run the bf16 backward kernels
     int no_small = 0;            // batches of <= 64 groups on the large-batch kernels instead of the small-batch form (csrc/small.cuh)
+    int fp8_head_f32 = 0;        // CP_FP8: the head's logits from the f32 MFMAs instead of the block-scaled 8-bit one (head.cuh, F8L)
 #ifdef CP_VARIANTS
     int no_ws = 0, no_wsk = 0, no_wsd = 0, no_wsd_st = 0, staged_r_epilogue = 0, ws32 = 0, wsd32 = 0, tn_w4 = 0, tn16 = 0,
         materialize_u8 = 0, no_proj_fused = 0;

@@ -63,7 +63,12 @@ __device__ __forceinline__ float head_qmax(float v) { v = fmaxf(v, __shfl_xor(v,
 __device__ __forceinline__ float head_exp2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (arguments <= 0 here, or tiny)
 __device__ __forceinline__ float head_log2(float x) { return __builtin_amdgcn_logf(x); }       // v_log_f32 (arguments in [1, 48])
 
-template <typename T, bool GLOVE = false, bool GNEG = false>
+// F8L (BASELINE config 4, "fp8 MFMA logits GEMM"; CP_FP8 workspaces, one-hot class table): the logits come from ONE block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 per 16x16 tile on e4m3 copies of z_hat and E_hat (the 16 dims in the first 16 of the 128 k slots
+// of lane group 0, scale 2^0) instead of four f32 MFMAs; loss, predictions and dl are those of the quantised logits, the two gradient
+// products keep the f32 operands (straight-through).  e4m3 resolves [0.5, 1) in steps of 1/16: a logit moves by ~0.025 rms.
+typedef __attribute__((ext_vector_type(8))) int head_i32x8;
+template <typename T, bool GLOVE = false, bool GNEG = false, bool F8L = false>
 __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
     using D = DT<T>;
     __shared__ float Eh[HEAD_T][HEAD_D];                               // normalised class table (one-hot path)
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
                 if (q == 0) En[wave][i] = ie;
             }
             e4 *= keep;
-            zA[t] = z4 * HEAD_LOG2E; eA[t] = e4;
+            zA[t] = F8L ? z4 : z4 * HEAD_LOG2E; eA[t] = e4;
             *(f32x4*)&Zs[wave][i][4 * q] = z4;
             *(f32x4*)&Es[wave][i][4 * q] = e4;
             if (q == 0) { Nz[wave][i] = iz; Cls[wave][i] = cls; }
@@ -156,15 +161,40 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
         __builtin_amdgcn_wave_barrier();
         // ---- L[ti][tj][r] = l2[16ti + 4q + r][16tj + c],  Lt[tj][ti][r] = l2[16ti + c][16tj + 4q + r],  l2 = logits * log2 e ------
         f32x4 L[3][3], Lt[3][3];
+        if constexpr (F8L) {
+            // lane group 0 carries row 16t + c of the operand: its 16 dims as 16 e4m3 bytes, k slots 0..15; every other slot is zero
+            head_i32x8 zq[3], eq[3];
 #pragma unroll
-        for (int ti = 0; ti < 3; ++ti)
+            for (int t = 0; t < 3; ++t) {
+                int zd[4], ed[4];
 #pragma unroll
-            for (int tj = 0; tj < 3; ++tj) {
-                f32x4 x = zero4, y = zero4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { x = head_mfma(zA[ti][k], eA[tj][k], x); y = head_mfma(eA[tj][k], zA[ti][k], y); }
-                L[ti][tj] = x; Lt[tj][ti] = y;
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 zv = *(const f32x4*)&Zs[wave][16 * t + c][4 * k], ev = *(const f32x4*)&Es[wave][16 * t + c][4 * k];
+                    zd[k] = __builtin_amdgcn_cvt_pk_fp8_f32(zv[2], zv[3], __builtin_amdgcn_cvt_pk_fp8_f32(zv[0], zv[1], 0, false), true);
+                    ed[k] = __builtin_amdgcn_cvt_pk_fp8_f32(ev[2], ev[3], __builtin_amdgcn_cvt_pk_fp8_f32(ev[0], ev[1], 0, false), true);
+                    if (q != 0) { zd[k] = 0; ed[k] = 0; }
+                }
+                zq[t] = (head_i32x8){zd[0], zd[1], zd[2], zd[3], 0, 0, 0, 0};
+                eq[t] = (head_i32x8){ed[0], ed[1], ed[2], ed[3], 0, 0, 0, 0};
             }
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) {
+                    L[ti][tj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(zq[ti], eq[tj], zero4, 0, 0, 0, 127, 0, 127) * HEAD_LOG2E;
+                    Lt[tj][ti] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(eq[tj], zq[ti], zero4, 0, 0, 0, 127, 0, 127) * HEAD_LOG2E;
+                }
+        } else {
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) {
+                    f32x4 x = zero4, y = zero4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { x = head_mfma(zA[ti][k], eA[tj][k], x); y = head_mfma(eA[tj][k], zA[ti][k], y); }
+                    L[ti][tj] = x; Lt[tj][ti] = y;
+                }
+        }
         // ---- row softmax on Lt (row i = 16ti + c of l lives down the registers (tj, r) and across q) --------------------------------
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {

@@ -96,7 +96,8 @@ const char* cp_last_error(void);
 /* Process-wide switches, for tests and measurements (never read from the environment on a launch path).  The product library
  * knows "unfused_bn_bwd" (BatchNorm + ReLU backward as its own pass behind every data gradient: the f32 path's order, on the
  * bf16 kernels), "unpaired_wgrad" (one weight-gradient launch per layer behind a dropout) and "fp8_bridge" (CP_FP8: expand the
- * saved 8-bit tensors to bf16 and run the bf16 backward kernels); value 0 / 1.  The tools-only build (make -C csrc variants,
+ * saved 8-bit tensors to bf16 and run the bf16 backward kernels), "no_small" (batches of <= 64 groups on the large-batch kernels) and
+ * "fp8_head_f32" (CP_FP8: the head's logits from the f32 matrix instruction instead of the block-scaled 8-bit one); value 0 / 1.  The tools-only build (make -C csrc variants,
  * cp_has_variants() == 1) also carries the superseded kernels with one switch each.  Unknown name: CP_ERR_ARG. */
 int cp_debug_set_option(const char* name, int32_t value);
 int cp_has_variants(void);

@@ -252,3 +252,47 @@ def test_against_the_bf16_path_at_bench_sizes(groups):
           f"{agree:.4f}, loss {res['fp8'][0]:.5f} vs {res['bf16'][0]:.5f}, cosine of the whole gradient {cos:.4f}")
     assert abs(res["fp8"][0] - res["bf16"][0]) < 0.01 * res["bf16"][0]
     assert cos > 0.9
+
+
+def test_head_logits_on_the_8bit_mfma():
+    """BASELINE config 4's "fp8 MFMA logits GEMM" (head.cuh, F8L): under dtype="fp8" the 41 x 41 logits of a group come from the
+    block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 copies of z_hat and E_hat; "fp8_head_f32" keeps the f32 products.  Same z
+    into both: the logits differ by the e4m3 rounding of two unit vectors (steps of 1/16 in [0.5, 1): ~0.025 rms on a sum of 16
+    products), the loss by well under 1 %, and the gradients -- whose two products keep the f32 operands -- by what the softmax
+    makes of that logit noise.  Against a torch emulation of the quantised product the logits agree to 1e-4.  Measured (round 3, 64
+    groups): max |d| 0.046, rms 0.0093, argmax agreement 0.953, loss 3.74100 vs 3.74079, cosine of dL/dE 0.99998."""
+    from contrastiveprosthetics_amd import _lib
+    B = 64
+    sd = nontrivial_sd(5, False)
+    e = make_engine(sd, False, "fp8")
+    x = (randn(3, (T, 12))[None] + randn(4, (B, T, 12))).reshape(-1, 12).cuda()
+    labels = torch.arange(T).repeat(B).cuda()
+    z = e.encoder_forward(x, training=True).clone()
+    res = {}
+    for f32_head in (0, 1):
+        _lib.check(e.lib.cp_debug_set_option(b"fp8_head_f32", f32_head), "cp_debug_set_option")
+        try:
+            e.grads.flat.zero_()
+            out, pred, logits = e.head(z, labels, 1, want_grad=True, want_logits=True)
+            torch.cuda.synchronize()
+            res[f32_head] = (out.clone(), pred.clone(), logits.clone(), e.grads.views["glove_net.easy.0.weight"].clone())
+        finally:
+            e.lib.cp_debug_set_option(b"fp8_head_f32", 0)
+    (o8, p8, l8, g8), (o32, p32, l32, g32) = res[0], res[1]
+    # the emulation: both unit vectors to e4m3, products and sums in f32
+    zh = z / z.norm(dim=-1, keepdim=True)
+    E = (e.values.views["glove_net.easy.0.weight"].t() + e.values.views["glove_net.easy.0.bias"][None]).float()
+    Eh = E / E.norm(dim=-1, keepdim=True)
+    emu = (e4m3(zh).reshape(B, T, 16) @ e4m3(Eh).t()[None])
+    d_emu = float((l8 - emu).abs().max())
+    d = (l8 - l32)
+    agree = float((p8 == p32).float().mean())
+    cos = float((g8.flatten().double() @ g32.flatten().double()) / (g8.norm().double() * g32.norm().double()))
+    print(f"\nhead logits, 8-bit MFMA vs f32 MFMA on the same z: max |d| {float(d.abs().max()):.4f} rms {float(d.pow(2).mean().sqrt()):.4f}, argmax agreement "
+          f"{agree:.4f}, loss {float(o8[0]):.5f} vs {float(o32[0]):.5f}, cosine of dL/dE {cos:.5f}; vs the torch emulation of the quantised product: {d_emu:.2e}")
+    # (the kernel normalises with z * (1 / |z|), torch with z / |z|: a component within an ulp of an e4m3 rounding boundary lands on the
+    #  other side, one step of a SMALL component -- 2^-12 at 0.002 -- times |e| ~ 0.25)
+    assert torch.isfinite(l8).all() and d_emu < 2e-4
+    assert float(d.pow(2).mean().sqrt()) < 0.05 and float(d.abs().max()) < 0.25
+    assert abs(float(o8[0]) - float(o32[0])) < 0.01 * float(o32[0])
+    assert cos > 0.98

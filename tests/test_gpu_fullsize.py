@@ -339,6 +339,11 @@ def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
     E = ew.t() + eb
     En = E / E.norm(dim=-1, keepdim=True)
     logits = zn.reshape(B, T, 16) @ En.t()
+    if FP8:
+        # BASELINE config 4's logits GEMM (head.cuh, F8L): both unit vectors rounded to e4m3 for the product, the gradient products on
+        # the f32 operands -- the straight-through form of exactly that
+        q8 = lambda t: t.detach().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+        logits = logits + ((q8(zn).reshape(B, T, 16) @ q8(En).t()) - logits).detach()
     tgt = torch.arange(T, device="cuda").repeat(B)
     loss = (torch.nn.functional.cross_entropy(logits.reshape(-1, T), tgt)
             + torch.nn.functional.cross_entropy(logits.transpose(1, 2).reshape(-1, T), tgt)) / 2
