@@ -1976,9 +1976,10 @@ extern "C" int cp_l2_adam_step(float* params_flat, const float* grads_flat, floa
     a.bc1 = (float)(1.0 - pow((double)h->beta1, (double)step_index));
     a.bc2 = (float)(1.0 - pow((double)h->beta2, (double)step_index));
     ProfScope ps(CP_K_OPT, (hipStream_t)stream);
-    if (int e = launch_norms(a, scratch, l2_out, (hipStream_t)stream)) return e;
-    hipLaunchKernelGGL(adam_kernel, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);
-    CKL("adam_kernel");
+    a.norm_partials = scratch; a.norms = scratch + a.total_chunks; a.l2_out = l2_out;
+    hipLaunchKernelGGL(l2_sumsq_kernel, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);      // (norms folded inside: optim.cuh)
+    CKL("l2 norms + adam_kernel");
     return 0;
 }
 
@@ -1996,9 +1997,10 @@ extern "C" int cp_l2_adam_step_graph(float* params_flat, const float* grads_flat
     a.bc1 = a.bc2 = 1.f;
     a.state = (const float*)state_dev;
     ProfScope ps(CP_K_OPT, (hipStream_t)stream);
-    if (int e = launch_norms(a, scratch, l2_out, (hipStream_t)stream)) return e;
-    hipLaunchKernelGGL(adam_kernel, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);
-    CKL("adam_kernel");
+    a.norm_partials = scratch; a.norms = scratch + a.total_chunks; a.l2_out = l2_out;
+    hipLaunchKernelGGL(l2_sumsq_kernel, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(a.total_chunks), dim3(256), 0, (hipStream_t)stream, a);      // (norms folded inside: optim.cuh)
+    CKL("l2 norms + adam_kernel");
     return 0;
 }
 
