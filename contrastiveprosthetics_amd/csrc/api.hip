@@ -728,49 +728,47 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
     const int tiles_m = (int)((N + SM_BM - 1) / SM_BM);
     {
         ProfScope ps(CP_K_PREP, st);
-        hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
-        SmCopyBatch cb{};
+        SmPrepBatch cb{};
         for (int i = 0; i < CP_N_FC; ++i) cb.job[i] = SmCopyJob{p->fc_w[i], base + w.wfc[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
         cb.job[CP_N_FC] = SmCopyJob{p->last_w, base + w.wlast, CP_D_E, 512, 32, 0};
         cb.njobs = CP_N_FC + 1; cb.zero = (long long*)(base + w.sm_acc); cb.nzero = 18 * 2 * 768;
-        hipLaunchKernelGGL((sm_weight_copy_kernel<T>), dim3(512, CP_N_FC + 2), dim3(256), 0, st, cb);
+        for (int i = 0; i < CP_N_FC; ++i) cb.tr[i] = TransposeJob{p->fc_w[i], base + w.wfc_t[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
+        cb.tr[CP_N_FC] = TransposeJob{p->last_w, base + w.wlast_t, CP_D_E, 512, 64, 0};
+        cb.ntrans = CP_N_FC + 1;
+        cb.conv2_w = p->conv2_w; cb.wc2_f = base + w.wc2_f; cb.wc2_d = base + w.wc2_d;
+        hipLaunchKernelGGL((sm_prep_kernel<T>), dim3(512, cb.njobs + 1 + cb.ntrans + 1), dim3(256), 0, st, cb);
         CKL("prep kernels (small)");
     }
-    // conv1 statistics (finalised by their own launch: conv2's kernel reads finished statistics) and conv2
-    {
-        constexpr int RPP = 256 / (64 / D::EPC);
-        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
-        const int g = (int)((need + passes - 1) / passes);
-        ProfScope ps(CP_K_CONV1_FWD, st);
-        hipLaunchKernelGGL((conv1_stats_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, partials, R12);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, partials, g, (double)R12, p->bn_g[0], p->bn_b[0],
-                           have_running ? bn->running_mean[0] : nullptr, have_running ? bn->running_var[0] : nullptr, upd, 0,
-                           c->bn_momentum, c->bn_eps, stats(0), 64, (const int*)nullptr);
-        CKL("conv1 (small)");
-    }
-    {
-        ConvArgs ca{};
-        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0);
-        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = act(1); ca.partials = partials; ca.n_windows = N;
-        const int g2 = conv_grid<T>(N);
-        ProfScope ps(CP_K_CONV2_FWD, st);
-        hipLaunchKernelGGL((conv2_strip_kernel<T, 0>), dim3(g2), dim3(256), 0, st, ca);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, partials, g2, (double)R12, p->bn_g[1], p->bn_b[1],
-                           have_running ? bn->running_mean[1] : nullptr, have_running ? bn->running_var[1] : nullptr, upd, 0,
-                           c->bn_momentum, c->bn_eps, stats(1), 64, (const int*)nullptr);
-        CKL("conv2 (small)");
-    }
-    // fc1..fc7 and the projection: each launch turns its input's two fixed-point totals per column into scale / shift itself
+    // conv1 statistics and conv2: fixed-point totals like the fc stack's -- conv2's kernel finalises BatchNorm1 in its prologue, fc1's
+    // launch finalises BatchNorm2 (no finalize launches)
     long long* accs = (long long*)(base + w.sm_acc);
     auto acc_of = [&](int l) { return accs + (size_t)l * 2 * 768; };
     auto bn_of = [&](int l) {
         SmBN b{};
-        b.acc = l >= 2 ? acc_of(l) : nullptr; b.C = kLayerC[l]; b.count = l < 2 ? (double)R12 : (double)N;
+        b.acc = acc_of(l); b.C = kLayerC[l]; b.count = l < 2 ? (double)R12 : (double)N;
         b.gamma = p->bn_g[l]; b.beta = p->bn_b[l]; b.stats = stats(l);
         b.running_mean = have_running ? bn->running_mean[l] : nullptr; b.running_var = have_running ? bn->running_var[l] : nullptr;
         b.update_running = upd; b.momentum = c->bn_momentum; b.eps = c->bn_eps;
         return b;
     };
+    {
+        constexpr int RPP = 256 / (64 / D::EPC);
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int g = (int)((need + passes - 1) / passes);
+        ProfScope ps(CP_K_CONV1_FWD, st);
+        hipLaunchKernelGGL((conv1_stats_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, partials, R12, acc_of(0));
+        CKL("conv1 (small)");
+    }
+    {
+        ConvArgs ca{};
+        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = nullptr; ca.bn1 = bn_of(0); ca.acc_out = acc_of(1);
+        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = act(1); ca.partials = partials; ca.n_windows = N;
+        const int g2 = conv_grid<T>(N);
+        ProfScope ps(CP_K_CONV2_FWD, st);
+        hipLaunchKernelGGL((conv2_strip_kernel<T, 0>), dim3(g2), dim3(256), 0, st, ca);
+        CKL("conv2 (small)");
+    }
+    // fc1..fc7 and the projection: each launch turns its input's two fixed-point totals per column into scale / shift itself
     for (int i = 0; i < CP_N_FC; ++i) {
         const int L = 2 + i, Lp = L - 1, K = fcK(i);
         SmFwdArgs a{};
@@ -804,14 +802,7 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     const int tiles_m = (int)((N + SM_BM - 1) / SM_BM);
-    {
-        ProfScope ps(CP_K_PREP, st);
-        TransposeBatch tb{};
-        for (int i = 0; i < CP_N_FC; ++i) tb.job[i] = TransposeJob{p->fc_w[i], base + w.wfc_t[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
-        tb.job[CP_N_FC] = TransposeJob{p->last_w, base + w.wlast_t, CP_D_E, 512, 64, 0};
-        hipLaunchKernelGGL((transpose_w_batch_kernel<T>), dim3(128, CP_N_FC + 1), dim3(256), 0, st, tb);
-        CKL("transpose_w_batch_kernel");
-    }
+    // (the transposed weights the data gradients read were made by the forward pass's preparation launch: sm_prep_kernel)
     long long* accs = (long long*)(base + w.sm_acc);
     auto gacc_of = [&](int l) { return accs + (size_t)(9 + l) * 2 * 768; };        // totals of (g, g r_l) for layer l's BatchNorm backward
     T* gb[2] = {(T*)(base + w.gbuf[0]), (T*)(base + w.gbuf[1])};
@@ -1438,14 +1429,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         return e == hipSuccess ? 0 : fail((int)e, what);
     };
 
-    {
-        ProfScope ps(CP_K_PREP, st);
-        TransposeBatch tb{};
-        for (int i = 0; i < CP_N_FC; ++i) tb.job[i] = TransposeJob{p->fc_w[i], base + w.wfc_t[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
-        tb.job[CP_N_FC] = TransposeJob{p->last_w, base + w.wlast_t, CP_D_E, 512, 64, 0};
-        hipLaunchKernelGGL((transpose_w_batch_kernel<T>), dim3(128, CP_N_FC + 1), dim3(256), 0, st, tb);
-        CKL("transpose_w_batch_kernel");
-    }
+    // (the transposed weights the data gradients read were made by the forward pass's preparation launch: sm_prep_kernel)
 
     T* dz = (T*)(base + w.dz);
     T* cur = (T*)(base + w.gbuf[0]);

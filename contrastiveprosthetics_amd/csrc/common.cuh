@@ -177,6 +177,53 @@ __device__ __forceinline__ uint4 bn_drop_chunk(const uint4& in, const float* __r
     return D::pack(v);
 }
 
+// ---- BatchNorm totals as fixed-point integers (the small-batch path, small.cuh) --------------------------------------------
+// fixed-point scales of the accumulators: activation sums (|sum| up to ~2,624 x 10^6 for sums of squares) and gradient sums
+#define SM_ACT_SHIFT 31
+#define SM_GRAD_SHIFT 40
+__device__ __forceinline__ void sm_acc_add(long long* acc, float s, int shift) {
+    // s * 2^shift is an integer-valued double wherever the f32's last bit is worth >= 2^-shift; smaller bits round away (<= 2^-shift)
+    atomicAdd((unsigned long long*)acc, (unsigned long long)__double2ll_rn((double)s * (double)(1ull << shift)));
+}
+__device__ __forceinline__ double sm_acc_get(const long long* acc, int shift) { return (double)*acc / (double)(1ull << shift); }
+
+struct SmBN {
+    const long long* acc;    // [2][C] totals (sum, sum of squares) as fixed point, or nullptr: `stats` is already final (conv2's BatchNorm)
+    int C;
+    double count;
+    const float* gamma;
+    const float* beta;
+    float* stats;            // [4][C]
+    float* running_mean;     // nullable
+    float* running_var;
+    int update_running;
+    float momentum, eps;
+};
+// one channel of such a BatchNorm, for a thread that needs a few of them in registers (the conv kernels at small batches): the arithmetic
+// of sm_finalize_stats (small.cuh) and bn_finalize_kernel; `writer` (one thread per channel in the whole grid) stores the statistics
+// and updates the running ones.
+__device__ __forceinline__ void sm_bn_channel(const SmBN& b, int c, bool writer, float& sc, float& sh) {
+    const double s1 = sm_acc_get(b.acc + c, SM_ACT_SHIFT), s2 = sm_acc_get(b.acc + b.C + c, SM_ACT_SHIFT);
+    const double mu = s1 / b.count;
+    double vb = s2 / b.count - mu * mu;
+    if (vb < 0) vb = 0;
+    const float mean = (float)mu, var = (float)vb;
+    const float invstd = 1.0f / sqrtf(var + b.eps);
+    sc = b.gamma[c] * invstd;
+    sh = b.beta[c] - mean * sc;
+    if (writer) {
+        b.stats[0 * b.C + c] = mean;
+        b.stats[1 * b.C + c] = invstd;
+        b.stats[2 * b.C + c] = sc;
+        b.stats[3 * b.C + c] = sh;
+        if (b.update_running && b.running_mean) {
+            const double unb = b.count > 1 ? vb * b.count / (b.count - 1) : vb;
+            b.running_mean[c] = (1.f - b.momentum) * b.running_mean[c] + b.momentum * mean;
+            b.running_var[c] = (1.f - b.momentum) * b.running_var[c] + b.momentum * (float)unb;
+        }
+    }
+}
+
 // ---- reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

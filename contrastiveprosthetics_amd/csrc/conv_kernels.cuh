@@ -31,6 +31,10 @@ struct ConvArgs {
     uint32_t* out_amax;
     float* partials;        // [grid][2][64] (fwd: sum, sumsq of r2; dgrad: sum g, sum g*r1) / wgrad: slabs [grid][64][192]
     int64_t n_windows;
+    // small batches (small.cuh), forward only: BatchNorm1 finalised HERE from conv1_stats_kernel's fixed-point totals (bn1.acc != nullptr
+    // replaces stats1; block 0 stores the statistics) and the output's totals added to acc_out instead of partial rows: no finalize launches
+    SmBN bn1;
+    long long* acc_out;     // [2][64] or nullptr
 };
 
 template <typename T> struct ConvGeo {
@@ -99,7 +103,7 @@ __device__ __forceinline__ void conv1_chunk(const float* __restrict__ x, int64_t
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ partials,
-                                                          int64_t rows) {
+                                                          int64_t rows, long long* __restrict__ acc = nullptr) {
     using G = ConvGeo<T>;
     constexpr int EPC = G::EPC, CPR = G::CPR, RPP = G::RPP;
     __shared__ float red[2][RPP][64];
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restric
         const int which = tid >> 6, c = tid & 63;
         float s = 0.f;
         for (int q = 0; q < RPP; ++q) s += red[which][q][c];
-        partials[((int64_t)blockIdx.x * 2 + which) * 64 + c] = s;
+        if (acc != nullptr) sm_acc_add(acc + which * 64 + c, s, SM_ACT_SHIFT);       // (small batches: order-independent integer totals)
+        else partials[((int64_t)blockIdx.x * 2 + which) * 64 + c] = s;
     }
 }
 
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
         bs[e] = a.b1[c];
         sc[e] = (MODE == 0 && a.stats1) ? a.stats1[2 * 64 + c] : 1.f;
         sh[e] = (MODE == 0 && a.stats1) ? a.stats1[3 * 64 + c] : 0.f;
+        if (MODE == 0 && a.bn1.acc != nullptr) sm_bn_channel(a.bn1, c, blockIdx.x == 0 && rr == 0, sc[e], sh[e]);
     }
     float b2v[4][4];                               // conv2 bias of this lane's 16 output features
 #pragma unroll
@@ -397,7 +403,8 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
         const int which = tid >> 6, c = tid & 63;
         float s = 0.f;
         for (int q = 0; q < RPP; ++q) s += red[(which * RPP + q) * 64 + c];
-        a.partials[((int64_t)blockIdx.x * 2 + which) * 64 + c] = s;
+        if (MODE == 0 && a.acc_out != nullptr) sm_acc_add(a.acc_out + which * 64 + c, s, SM_ACT_SHIFT);
+        else a.partials[((int64_t)blockIdx.x * 2 + which) * 64 + c] = s;
     }
 }
 

@@ -191,14 +191,12 @@ struct TransposeBatch { TransposeJob job[8]; };
 // (coalesced T).  grid (max tiles of a job, jobs), 256 threads.  (The first version read W with a stride of K floats
 // between neighbouring threads and divided a 64-bit index per element: 16.6 us for the eight matrices, now 11.5.)
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_w_batch_kernel(TransposeBatch b) {
+__device__ __forceinline__ void transpose_w_job(const TransposeJob& j, int bx, int gx, float (*tile)[65]) {
     using D = DT<T>;
-    __shared__ float tile[64][65];
-    const TransposeJob j = b.job[blockIdx.y];
     const int tiles_j = j.ld_out / 64, tiles_k = j.K / 64;
     T* out = (T*)j.out;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (int t = blockIdx.x; t < tiles_j * tiles_k; t += gridDim.x) {
+    for (int t = bx; t < tiles_j * tiles_k; t += gx) {
         const int j0 = (t % tiles_j) * 64, k0 = (t / tiles_j) * 64;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -215,18 +213,27 @@ __global__ __launch_bounds__(256) void transpose_w_batch_kernel(TransposeBatch b
         __syncthreads();
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_w_batch_kernel(TransposeBatch b) {
+    __shared__ float tile[64][65];
+    transpose_w_job<T>(b.job[blockIdx.y], blockIdx.x, gridDim.x, tile);
+}
 
 // conv2 weights (64,64,3,3): kernel row 1 only.
 //   fwd[o][tap*64 + i]  = W[o][i][1][tap]
 //   dgr[i][tap*64 + o]  = W[o][i][1][2 - tap]     (flipped taps for the data gradient)
 template <typename T>
-__global__ void prep_conv2_kernel(const float* __restrict__ W, T* __restrict__ fwd, T* __restrict__ dgr) {
+__device__ __forceinline__ void prep_conv2_body(const float* __restrict__ W, T* __restrict__ fwd, T* __restrict__ dgr, int first, int stride) {
     using D = DT<T>;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 64 * 192; idx += gridDim.x * blockDim.x) {
+    for (int idx = first; idx < 64 * 192; idx += stride) {
         const int a = idx / 192, rem = idx % 192, tap = rem / 64, b = rem % 64;
         D::store(fwd + idx, W[((a * 64 + b) * 3 + 1) * 3 + tap]);
         D::store(dgr + idx, W[((b * 64 + a) * 3 + 1) * 3 + (2 - tap)]);
     }
+}
+template <typename T>
+__global__ void prep_conv2_kernel(const float* __restrict__ W, T* __restrict__ fwd, T* __restrict__ dgr) {
+    prep_conv2_body<T>(W, fwd, dgr, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ------------------------------------------------------------------------------------

@@ -31,27 +31,7 @@
 // partials: [nrows][2][C] (sum, sum of squares).  All threads of the block take part; s_lds / t_lds: scale = gamma * invstd,
 // shift = beta - mean * scale.  The `writer` block also stores [mean, invstd, scale, shift] and updates the running statistics
 // (momentum, unbiased variance), exactly as bn_finalize_kernel does.
-// fixed-point scales of the accumulators: activation sums (|sum| up to ~2,624 x 10^6 for sums of squares) and gradient sums
-#define SM_ACT_SHIFT 31
-#define SM_GRAD_SHIFT 40
-__device__ __forceinline__ void sm_acc_add(long long* acc, float s, int shift) {
-    // s * 2^shift is an integer-valued double wherever the f32's last bit is worth >= 2^-shift; smaller bits round away (<= 2^-shift)
-    atomicAdd((unsigned long long*)acc, (unsigned long long)__double2ll_rn((double)s * (double)(1ull << shift)));
-}
-__device__ __forceinline__ double sm_acc_get(const long long* acc, int shift) { return (double)*acc / (double)(1ull << shift); }
-
-struct SmBN {
-    const long long* acc;    // [2][C] totals (sum, sum of squares) as fixed point, or nullptr: `stats` is already final (conv2's BatchNorm)
-    int C;
-    double count;
-    const float* gamma;
-    const float* beta;
-    float* stats;            // [4][C]
-    float* running_mean;     // nullable
-    float* running_var;
-    int update_running;
-    float momentum, eps;
-};
+// (SM_ACT_SHIFT, SM_GRAD_SHIFT, sm_acc_add / sm_acc_get, SmBN, sm_bn_channel: common.cuh -- the conv kernels use them too)
 template <int NT>
 __device__ __forceinline__ void sm_finalize_stats(const SmBN& b, float* s_lds, float* t_lds, bool writer) {
     for (int c = threadIdx.x; c < b.C; c += NT) {
@@ -688,20 +668,34 @@ __global__ __launch_bounds__(256) void sm_reduce_grads_kernel(SmReduceBatch b) {
 
 // this step's copies of the fc weights in the compute dtype, one launch: job j = {W f32 [F][K], out T [rows_out][K]}; mode 1 (fc1):
 // columns in the internal order k' = w*64 + c of the reference's k = c*12 + w.  grid (512, jobs).
+// ONE weight-preparation launch per step (grid (512, njobs + 1 + ntrans + 1)): the T copies of the fc weights and the projection
+// (forward operands, fc1 in the internal column order), the step's BatchNorm accumulators zeroed, the transposed copies the backward
+// pass's data gradients read (they depend on the parameters only, so they can be made before the forward pass needs nothing of them),
+// and conv2's two tap-major weight images.  (Three launches until round 3: 20 us of a 300 us step.)
 struct SmCopyJob { const float* W; void* out; int F, K, rows_out, mode; };
-struct SmCopyBatch { SmCopyJob job[8]; int njobs; long long* zero; int nzero; };
+struct SmPrepBatch {
+    SmCopyJob job[8]; int njobs; long long* zero; int nzero;
+    TransposeJob tr[8]; int ntrans;
+    const float* conv2_w; void* wc2_f; void* wc2_d;
+};
 template <typename T>
-__global__ __launch_bounds__(256) void sm_weight_copy_kernel(SmCopyBatch b) {
+__global__ __launch_bounds__(256) void sm_prep_kernel(SmPrepBatch b) {
     using D = DT<T>;
-    if ((int)blockIdx.y == b.njobs) {                       // the step's BatchNorm accumulators (forward and backward) start at zero
+    __shared__ float tile[64][65];
+    const int y = blockIdx.y;
+    if (y < b.njobs) {
+        const SmCopyJob jb = b.job[y];
+        const int j = blockIdx.x;
+        if (j >= jb.rows_out) return;
+        for (int kp = threadIdx.x; kp < jb.K; kp += 256) {
+            const int k = jb.mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;
+            D::store((T*)jb.out + (int64_t)j * jb.K + kp, j < jb.F ? jb.W[(int64_t)j * jb.K + k] : 0.f);
+        }
+    } else if (y == b.njobs) {                              // the step's BatchNorm accumulators (forward and backward) start at zero
         for (int i = blockIdx.x * 256 + threadIdx.x; i < b.nzero; i += gridDim.x * 256) b.zero[i] = 0;
-        return;
-    }
-    const SmCopyJob jb = b.job[blockIdx.y];
-    const int j = blockIdx.x;
-    if (j >= jb.rows_out) return;
-    for (int kp = threadIdx.x; kp < jb.K; kp += 256) {
-        const int k = jb.mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;
-        D::store((T*)jb.out + (int64_t)j * jb.K + kp, j < jb.F ? jb.W[(int64_t)j * jb.K + k] : 0.f);
+    } else if (y <= b.njobs + b.ntrans) {
+        if (blockIdx.x < 128) transpose_w_job<T>(b.tr[y - b.njobs - 1], blockIdx.x, 128, tile);
+    } else {
+        if (blockIdx.x < 48) prep_conv2_body<T>(b.conv2_w, (T*)b.wc2_f, (T*)b.wc2_d, blockIdx.x * 256 + threadIdx.x, 48 * 256);
     }
 }
