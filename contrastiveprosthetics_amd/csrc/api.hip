@@ -1429,7 +1429,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         return e == hipSuccess ? 0 : fail((int)e, what);
     };
 
-    // (the transposed weights the data gradients read were made by the forward pass's preparation launch: sm_prep_kernel)
+    {
+        ProfScope ps(CP_K_PREP, st);
+        TransposeBatch tb{};
+        for (int i = 0; i < CP_N_FC; ++i) tb.job[i] = TransposeJob{p->fc_w[i], base + w.wfc_t[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
+        tb.job[CP_N_FC] = TransposeJob{p->last_w, base + w.wlast_t, CP_D_E, 512, 64, 0};
+        hipLaunchKernelGGL((transpose_w_batch_kernel<T>), dim3(128, CP_N_FC + 1), dim3(256), 0, st, tb);
+        CKL("transpose_w_batch_kernel");
+    }
 
     T* dz = (T*)(base + w.dz);
     T* cur = (T*)(base + w.gbuf[0]);

@@ -187,7 +187,7 @@ def test_backward_8bit_against_the_bf16_bridge(dp, B):
         finally:
             e.lib.cp_debug_set_option(b"fp8_bridge", 0)
         grads[mode] = {k: v.clone().cpu().double() for k, v in e.grads.views.items()}
-        assert all(bool(torch.isfinite(v).all()) for v in grads[mode].values()), mode
+        assert all(bool(torch.isfinite(v).all()) for v in grads[mode].values()), (mode, [k for k, v in grads[mode].items() if not torch.isfinite(v).all()])
     worst = (1.0, "")
     report, bad = [], []
     for k, gb in grads["bridge"].items():
