@@ -482,6 +482,32 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, threads=min(16, os.cpu_count() or 1))
             rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        if world == 1 and not rehearse and args.class_encoder == "onehot" and not args.main_only and args.dtype == "bf16":
+            # BASELINE config 4's storage on the same workload, same run (its own line: python bench.py --dtype fp8): 8-bit activations,
+            # weights and gradients on the block-scaled MFMA.  Parity unpinned by construction; it is not `value`.
+            e8 = Engine(adabn=args.adabn, dtype="fp8", dp_emg=args.dp_emg, device=dev, seed=1000)
+            e8.init_parameters(seed=42)
+            e8.workspace(N)
+
+            def step8(i):
+                x = e8.gather(table, emg_rand, perms[i], 1)
+                z = e8.encoder_forward(x, training=True)
+                o, _, _ = e8.head(z, labels, 1, want_grad=True)
+                e8.encoder_backward(x)
+                e8.adam_step(params)
+                return o
+            for i in range(4):
+                step8(i)
+            torch.cuda.synchronize(dev)
+            k8 = max(5, args.steps // 2)
+            t8 = time.perf_counter()
+            for i in range(k8):
+                o8 = step8(args.warmup + (i % args.steps))
+            torch.cuda.synchronize(dev)
+            el8 = time.perf_counter() - t8
+            rec["config4_fp8"] = dict(ms_per_step=1e3 * el8 / k8, value=N * k8 / el8, unit="windows/s", steps=k8, loss=float(o8[0]),
+                                      note="same workload with 8-bit storage + MX MFMA (CP_FP8), parity unpinned by construction; full line: bench.py --dtype fp8")
+            del e8
         if world == 1 and not rehearse and args.class_encoder == "onehot" and not args.main_only:
             rec["small_batch"] = small_batch_record(dev, args.dtype)
             if "cpu_baseline" in rec and "b8" in rec["cpu_baseline"]:
