@@ -270,6 +270,9 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
         fsrc[q] = (uint32_t)(row * K + (((pc & ~15) | ((pc ^ row) & 15)) << 4));
     }
     auto fetch_unit = [&](uint32_t tile_soff, int buf, int q) {
+#ifdef WS8_NO_FETCH
+        tile_soff = 0xFFF00000u;                    // ablation build (tools only): every fetch is out of range (zeros, no memory traffic)
+#endif
         bufl16_lds(a_rsrc, fsrc[q], tile_soff, lds0 + buf * TILE_BYTES + (wave * UPW + q) * 1024);
     };
     auto row0 = [&](int ti) -> int64_t { return ((int64_t)ti * stride + first) * RT; };
@@ -285,6 +288,13 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
 
     // epilogue of sample tile st of a finished tile: clamp(relu), sums, maximum, convert, transpose over the sample's 4 lanes, store
     auto epi_st = [&](f32x4_t (&old)[4][ST], int st, uint32_t s_old, bool live) {
+#ifdef WS8_NO_EPI
+        // ablation build (tools only): keep the finished accumulators alive, do nothing with them
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) asm volatile("" :: "v"(old[ft][st]));
+        (void)s_old; (void)live;
+        return;
+#endif
         uint32_t d[4];
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
