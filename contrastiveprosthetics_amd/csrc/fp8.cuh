@@ -362,7 +362,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
                 if (!PF2 && kb + 1 < KB) fa[0][st] = load_frag(At, kb + 1, st);
             }
             if constexpr (WITH_EPI && WOVEN)
-                if (kb >= EPI_KB0) epi_st(old, kb - EPI_KB0, (uint32_t)(m_old * a.F), true);
+                if (kb >= EPI_KB0) {
+                    epi_st(old, kb - EPI_KB0, (uint32_t)(m_old * a.F), true);
+                    // (forcing one MFMA, then 3 or 5 of these vector instructions in its shadow with sched_group_barrier: 56.4 / 75.0 us
+                    //  against 57.5 on the same box -- as in bf16, the two pipes do not overlap for free)
+                }
         }
         if constexpr (WITH_EPI && !WOVEN) {
             __builtin_amdgcn_sched_barrier(0);
