@@ -726,6 +726,7 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     const int tiles_m = (int)((N + SM_BM - 1) / SM_BM);
+    const bool ks = sm_ksplit<T>(N);                   // f32, few row tiles: 64-feature tiles with the contraction split over wave pairs
     {
         ProfScope ps(CP_K_PREP, st);
         SmPrepBatch cb{};
@@ -776,7 +777,12 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
         a.bn_in = bn_of(Lp); a.smod = kLayerC[Lp]; a.N = N; a.K = K;
         if (drop && Lp >= 5) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         ProfScope ps(K == 512 ? CP_K_FC_FWD_WS : CP_K_FC_FWD, st);
-        hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0>), dim3(tiles_m * (512 / SM_BN)), dim3(256), 0, st, a);
+        if constexpr (sizeof(T) == 4) {
+            if (ks) hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0, true>), dim3(tiles_m * (512 / SmTile<true>::BN)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0>), dim3(tiles_m * (512 / SM_BN)), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0>), dim3(tiles_m * (512 / SM_BN)), dim3(256), 0, st, a);
+        }
         CKL("sm_fc_fwd_kernel");
     }
     {
@@ -802,6 +808,8 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     const int tiles_m = (int)((N + SM_BM - 1) / SM_BM);
+    const bool ks = sm_ksplit<T>(N);
+    const int bn_tile = ks ? SmTile<true>::BN : SM_BN;
     // (the transposed weights the data gradients read were made by the forward pass's preparation launch: sm_prep_kernel)
     long long* accs = (long long*)(base + w.sm_acc);
     auto gacc_of = [&](int l) { return accs + (size_t)(9 + l) * 2 * 768; };        // totals of (g, g r_l) for layer l's BatchNorm backward
@@ -831,10 +839,15 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
         SmBwdArgs a{};
         a.Gin = base + w.dz; a.Wt = base + w.wlast_t; a.Rp = act(8); a.stats_p = stats(8); a.Gout = gb[cur]; a.out_acc = gacc_of(8);
         a.dW = grad_dst(g->last_w, CP_D_E * 512); a.db = nullptr; a.slab_stride = kSlabStride; a.rows_per_split = rps; a.splits = splits;
-        a.p_valid = CP_D_E; a.N = N; a.K = 512; a.smod = 512; a.wmode = 0; a.n_dgrad = tiles_m * (512 / SM_BN);
+        a.p_valid = CP_D_E; a.N = N; a.K = 512; a.smod = 512; a.wmode = 0; a.n_dgrad = tiles_m * (512 / bn_tile);
         if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         ProfScope ps(CP_K_PROJ_BWD, st);
-        hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
+        if constexpr (sizeof(T) == 4) {
+            if (ks) hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
+        }
         CKL("sm_fc_bwd_kernel<proj>");
     }
     for (int L = 8; L >= 2; --L) {
@@ -847,10 +860,15 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
         else a.out_acc = gacc_of(Lp);
         a.dW = grad_dst(g->fc_w[i], 512 * K); a.db = grad_dst(g->fc_b[i], 512);
         a.slab_stride = kSlabStride; a.rows_per_split = rps; a.splits = splits; a.p_valid = 512;
-        a.N = N; a.K = K; a.smod = kLayerC[Lp]; a.wmode = i == 0 ? 1 : 0; a.n_dgrad = tiles_m * (K / SM_BN);
+        a.N = N; a.K = K; a.smod = kLayerC[Lp]; a.wmode = i == 0 ? 1 : 0; a.n_dgrad = tiles_m * (K / bn_tile);
         if (drop && Lp >= 5) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         ProfScope ps(CP_K_FC_DGRAD, st);
-        hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
+        if constexpr (sizeof(T) == 4) {
+            if (ks) hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false, true>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
+        }
         CKL("sm_fc_bwd_kernel");
         cur ^= 1;
     }

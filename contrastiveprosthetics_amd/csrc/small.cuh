@@ -109,9 +109,16 @@ __device__ __forceinline__ uint4 sm_bn_drop_chunk(const uint4& in, const float* 
 // ahead, 21 us per layer; two sub-tiles, loads two steps ahead but TRANSFORMED in the load phase (every step waited for the load it had
 // just issued) 6.5 us; raw loads, transforms at store time 4.6 us; this form: see DESIGN.md 7g.
 template <typename T> struct SmNsub { static constexpr int v = sizeof(T) == 2 ? 4 : 2; };
+// f32: a wave's k loop is a chain of 64-cycle v_mfma_f32_32x32x2_f32 on one accumulator (256 of them for K = 512: 7.8 us at best, 13 us
+// measured, of a 17 us launch), so the contraction is split over wave PAIRS: 64-feature tiles, wave w = feature group w & 1, k half
+// w >> 1 of every 32-deep sub-tile; the two partial tiles meet in LDS in the epilogue (0.45 -> 0.37 ms per step at 8 groups).
+// bf16, and f32 from 25 groups up: 128-feature tiles, no split (at 32 groups the split's 328 workgroups need a second round: 0.55 -> 0.60 ms).
+// (the split doubles the workgroups: it is used while they still fit one round of the 256 CUs -- sm_ksplit() -- f32 only)
+template <bool KS> struct SmTile { static constexpr int BN = KS ? 64 : SM_BN; static constexpr bool KSPLIT = KS; };
+template <typename T> static inline bool sm_ksplit(int64_t n_windows) { return sizeof(T) == 4 && (n_windows + SM_BM - 1) / SM_BM * 8 <= 256; }
 // NT: acc += A'[32 rows][K] x W[BN rows][K]^T for the wave's 32 x 32 piece (W rows wrow .. wrow+31).  loadA(sub) / loadW(sub, i) return the
 // thread's 16-byte chunk (row tid >> 3 [+ 32 i], chunk tid & 7) of sub-tile `sub`; xformA(raw, sub) turns the raw A chunk into the operand.
-template <typename T, int BN, typename RawA, typename FA, typename XA, typename FW, typename Mid>
+template <typename T, int BN, typename RawA, bool KSPLIT = false, typename FA, typename XA, typename FW, typename Mid>
 __device__ __forceinline__ void sm_nt_loop(f32x16& acc, unsigned char* smem, int nsub, FA&& loadA, XA&& xformA, FW&& loadW, int wrow, bool do_mma,
                                            Mid&& mid, long long* dbg = nullptr) {
     constexpr int NSUB = SmNsub<T>::v;
@@ -150,7 +157,8 @@ __device__ __forceinline__ void sm_nt_loop(f32x16& acc, unsigned char* smem, int
             const unsigned char* As = smem + u * SUB;
             const unsigned char* Ws = As + A_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int kq = 0; kq < (KSPLIT ? 2 : 4); ++kq) {
+                const int ks = KSPLIT ? 2 * (int)(threadIdx.x >> 7) + kq : kq;      // KSPLIT: waves 0, 1 the first half of the sub-tile, 2, 3 the second
                 const uint4 fw = *(const uint4*)(Ws + lds_tile_off(wrow + r, 2 * ks + h));
                 const uint4 fs = *(const uint4*)(As + lds_tile_off(r, 2 * ks + h));
                 mma_chunk<T>(fw, fs, acc);
@@ -196,7 +204,8 @@ __device__ __forceinline__ void sm_nt_loop(f32x16& acc, unsigned char* smem, int
 template <typename T, int BN> struct SmNT {
     static constexpr int LOOP_BYTES = SmNsub<T>::v * (SM_BM * 128 + BN * 128);
     static constexpr int C_PITCH = BN * (int)sizeof(T) + 16, C_BYTES = SM_BM * C_PITCH, RED_BYTES = 2 * 256 * DT<T>::EPC * 4;
-    static constexpr int BYTES = LOOP_BYTES > C_BYTES + RED_BYTES ? LOOP_BYTES : C_BYTES + RED_BYTES;
+    static constexpr int EPI_BYTES = 2 * C_BYTES + RED_BYTES;            // (two images: the k halves of a split contraction)
+    static constexpr int BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
 };
 
 // TN: acc += X'[rows][64 cols]^T x Y'[rows][64 cols] over the rows m_begin .. m_end of both operands (sub-steps of 32 rows), for the wave's
@@ -285,7 +294,8 @@ template <typename T> struct SmTN {
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward of one fc layer (MODE 0):  r_out = relu(dropout(BN_in(r_in)) W^T + b), partial BatchNorm sums of r_out per row tile;
 // MODE 1 (projection): z = dropout(BN_in(r_in)) W_last^T, f32, 16 valid features of a 32-row padded weight, no sums.
-// grid = tiles_m * (F / SM_BN) (MODE 1: tiles_m); 256 threads = 4 waves, wave w = features f0 + 32 w .. +31 of the 32-row tile.
+// grid = tiles_m * (F / SmTile<KS>::BN) (MODE 1: tiles_m); 256 threads = 4 waves, bf16: wave w = features f0 + 32 w .. +31 of the 32-row tile;
+// f32: wave w = features f0 + 32 (w & 1) .. +31, k half w >> 1 (SmTile).
 // ---------------------------------------------------------------------------------------------------------------------------
 struct SmFwdArgs {
     const void* A;           // [N][K] T: the previous layer's stored post-ReLU output
@@ -312,7 +322,7 @@ __device__ __forceinline__ void sm_store_tile(unsigned char* smem, void* Cout, i
     constexpr int CPR = BN / EPC, RPP = 256 / CPR;
     const int tid = threadIdx.x;
     unsigned char* Cs = smem;
-    float* red = (float*)(smem + C_BYTES);
+    float* red = (float*)(smem + 2 * C_BYTES);
     const int cc = tid % CPR, rr = tid / CPR;
     float s1[EPC], s2[EPC];
 #pragma unroll
@@ -334,7 +344,7 @@ __device__ __forceinline__ void sm_store_tile(unsigned char* smem, void* Cout, i
         red[(1 * RPP + rr) * BN + cc * EPC + e] = s2[e];
     }
     __syncthreads();
-    {
+    if (tid < 2 * BN) {
         const int which = tid / BN, col = tid % BN;
         float s = 0.f;
 #pragma unroll
@@ -344,10 +354,12 @@ __device__ __forceinline__ void sm_store_tile(unsigned char* smem, void* Cout, i
     }
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool KS = false>
 __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
     using D = DT<T>;
-    constexpr int EPC = D::EPC, BK = D::BK, BM = SM_BM, BN = MODE == 0 ? SM_BN : 32;
+    constexpr int EPC = D::EPC, BK = D::BK, BM = SM_BM, BN = MODE == 0 ? SmTile<KS>::BN : 32;
+    constexpr bool KSPLIT = MODE == 0 && KS;
+    static_assert(!KS || sizeof(T) == 4, "the k split is the f32 form");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SmNT<T, BN>::BYTES];
     __shared__ __attribute__((aligned(16))) float s_in[512], t_in[512];
 
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-    sm_nt_loop<T, BN, uint4>(
+    sm_nt_loop<T, BN, uint4, KSPLIT>(
         acc, smem, a.K / BK,
         [&](int sub) -> uint4 { return *(const uint4*)(Ag + mc_st * a.K + sub * BK + sc * EPC); },
         [&](const uint4& raw, int sub) -> uint4 {
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
             return m_st < a.N ? v : make_uint4(0, 0, 0, 0);
         },
         [&](int sub, int i) -> uint4 { return *(const uint4*)(Wg + (int64_t)(f0 + sr + 32 * i) * a.K + sub * BK + sc * EPC); },
-        MODE == 0 ? wave * 32 : 0, MODE == 0 || wave == 0,
+        MODE == 0 ? (KSPLIT ? (wave & 1) * 32 : wave * 32) : 0, MODE == 0 || wave == 0,
         [&]() {                                           // (under the first two steps' loads)
             sm_finalize_stats<256>(a.bn_in, s_in, t_in, blockIdx.x == 0);
             stamp(1);
@@ -411,21 +423,37 @@ __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
         }
         return;
     } else {
-        constexpr int C_PITCH = SmNT<T, BN>::C_PITCH;
+        constexpr int C_PITCH = SmNT<T, BN>::C_PITCH, C_BYTES = SmNT<T, BN>::C_BYTES;
+        if constexpr (KSPLIT) {
+            // raw partial sums of this wave's k half into image (wave >> 1); bias, ReLU and the statistics when the halves meet below
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int fl = wave * 32 + 8 * q + 4 * h;
-            float v[4];
+            for (int q = 0; q < 4; ++q) {
+                const int fl = (wave & 1) * 32 + 8 * q + 4 * h;
+                *(float4*)(smem + (wave >> 1) * C_BYTES + r * C_PITCH + fl * 4) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * q + e] + a.bias[f0 + fl + e], 0.f);
-            unsigned char* dst = smem + r * C_PITCH + fl * (int)sizeof(T);
-            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-            else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            for (int q = 0; q < 4; ++q) {
+                const int fl = wave * 32 + 8 * q + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * q + e] + a.bias[f0 + fl + e], 0.f);
+                unsigned char* dst = smem + r * C_PITCH + fl * (int)sizeof(T);
+                if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
         __syncthreads();
-        sm_store_tile<T, BN>(smem, a.C, 512, m0, a.N, f0, nullptr, tile_m, 512, a.out_acc, SM_ACT_SHIFT, [&](uint4& c, int64_t, int, float* s1, float* s2) {
+        sm_store_tile<T, BN>(smem, a.C, 512, m0, a.N, f0, nullptr, tile_m, 512, a.out_acc, SM_ACT_SHIFT, [&](uint4& c, int64_t m, int f, float* s1, float* s2) {
             float v[EPC];
             D::unpack(c, v);
+            if constexpr (KSPLIT) {
+                const float4 o = *(const float4*)(smem + C_BYTES + (int)(m - m0) * C_PITCH + (f - f0) * 4);
+                const float4 b = *(const float4*)(a.bias + f);
+                v[0] = fmaxf(v[0] + o.x + b.x, 0.f); v[1] = fmaxf(v[1] + o.y + b.y, 0.f);
+                v[2] = fmaxf(v[2] + o.z + b.z, 0.f); v[3] = fmaxf(v[3] + o.w + b.w, 0.f);
+                c = D::pack(v);
+            }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
         });
@@ -491,10 +519,12 @@ __device__ __forceinline__ uint4 sm_bnrelu_bwd_chunk(const uint4& gq, const uint
     return D::pack(g);
 }
 
-template <typename T, bool PROJ>
+template <typename T, bool PROJ, bool KS = false>
 __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
     using D = DT<T>;
-    constexpr int EPC = D::EPC, BK = D::BK, BM = SM_BM, BN = SM_BN;
+    constexpr int EPC = D::EPC, BK = D::BK, BM = SM_BM, BN = SmTile<KS>::BN;
+    constexpr bool KSPLIT = KS;
+    static_assert(!KS || sizeof(T) == 4, "the k split is the f32 form");
     constexpr int KC = PROJ ? 64 : 512;                    // contraction of the data gradient = width of Gin
     constexpr int LDS_BYTES = SmNT<T, BN>::BYTES > SmTN<T>::BYTES ? SmNT<T, BN>::BYTES : SmTN<T>::BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -550,7 +580,7 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-        sm_nt_loop<T, BN, RawA>(
+        sm_nt_loop<T, BN, RawA, KSPLIT>(
             acc, smem, KC / BK,
             [&](int sub) -> RawA { return a_load(mc_st, sub * BK + sc * EPC); },
             [&](const RawA& raw, int sub) -> uint4 {
@@ -558,12 +588,12 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
                 return m_st < a.N ? v : make_uint4(0, 0, 0, 0);
             },
             [&](int sub, int i) -> uint4 { return *(const uint4*)(Wg + (int64_t)(k0o + sr + 32 * i) * KC + sub * BK + sc * EPC); },
-            wave * 32, true, prologue);
-        constexpr int C_PITCH = SmNT<T, BN>::C_PITCH;
+            KSPLIT ? (wave & 1) * 32 : wave * 32, true, prologue);
+        constexpr int C_PITCH = SmNT<T, BN>::C_PITCH, C_BYTES = SmNT<T, BN>::C_BYTES;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int fl = wave * 32 + 8 * q + 4 * h;
-            unsigned char* dst = smem + r * C_PITCH + fl * (int)sizeof(T);
+            const int fl = (KSPLIT ? (wave & 1) : wave) * 32 + 8 * q + 4 * h;
+            unsigned char* dst = smem + (KSPLIT ? (wave >> 1) * C_BYTES : 0) + r * C_PITCH + fl * (int)sizeof(T);      // (KSPLIT: image = k half)
             if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2bf(acc[4 * q], acc[4 * q + 1]), pack2bf(acc[4 * q + 2], acc[4 * q + 3]));
             else *(float4*)dst = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         }
@@ -572,6 +602,10 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
         sm_store_tile<T, BN>(smem, a.Gout, a.K, m0, a.N, k0o, a.out_partials, tile_m, a.K, a.out_acc, SM_GRAD_SHIFT, [&](uint4& c, int64_t m, int k, float* s1, float* s2) {
             float v[EPC], rv[EPC];
             D::unpack(c, v);
+            if constexpr (KSPLIT) {                         // the other k half of the product
+                const float4 o = *(const float4*)(smem + C_BYTES + (int)(m - m0) * C_PITCH + (k - k0o) * 4);
+                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+            }
             D::unpack(*(const uint4*)(Rpg + m * a.K + k), rv);
             if (a.dp_thresh != 0) {
 #pragma unroll
@@ -580,6 +614,8 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
                     v[e] *= dropout_scale(pr, 0, a.dp_thresh, a.dp_inv_keep);
                     v[e + 1] *= dropout_scale(pr, 1, a.dp_thresh, a.dp_inv_keep);
                 }
+                c = D::pack(v);
+            } else if constexpr (KSPLIT) {
                 c = D::pack(v);
             }
 #pragma unroll
