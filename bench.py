@@ -213,6 +213,25 @@ def small_batch_record(dev, dtype: str, seconds: float = 0.6):
     return out
 
 
+def _timed_mode(mode, k_other, step, barrier, args, use_dist, dist, dev, world, N):
+    """ms per step of the training step under another loss workload (bench.py `other_steps`)."""
+    for i in range(2):
+        step(i, mode)
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(k_other):
+        step(args.warmup + (i % args.steps), mode)
+    barrier()
+    el = time.perf_counter() - t1
+    if use_dist:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return dict(ms_per_step=1e3 * el / k_other, value=world * N * k_other / el, steps=k_other,
+                loss={"off": "reference per-group loss", "gather": "global negatives, z all-gather",
+                      "reduce": "global negatives, partial sums + two 64-float all-reduces"}[mode])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,23 +392,12 @@ def main():
     if args.class_encoder == "onehot" and not args.main_only:
         k_other = max(4, args.steps // 2)
         for mode in ("off", "gather", "reduce"):
-            if mode == gn:
+            if mode == gn or "error" in other_steps:
                 continue
-            for i in range(2):
-                step(i, mode)
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(k_other):
-                step(args.warmup + (i % args.steps), mode)
-            barrier()
-            el = time.perf_counter() - t1
-            if use_dist:
-                t = torch.tensor([el], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            other_steps[mode] = dict(ms_per_step=1e3 * el / k_other, value=world * N * k_other / el, steps=k_other,
-                                     loss={"off": "reference per-group loss", "gather": "global negatives, z all-gather",
-                                           "reduce": "global negatives, partial sums + two 64-float all-reduces"}[mode])
+            try:
+                other_steps[mode] = _timed_mode(mode, k_other, step, barrier, args, use_dist, dist, dev, world, N)
+            except Exception as ex:                           # the side records never cost the line its main measurement
+                other_steps["error"] = f"{mode}: {type(ex).__name__}: {ex}"
 
     if args.breakdown and rank == 0:
         eng.profile_enable(None, max_records=4096)
@@ -483,35 +491,41 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, threads=min(16, os.cpu_count() or 1))
             rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
         if world == 1 and not rehearse and args.class_encoder == "onehot" and not args.main_only and args.dtype == "bf16":
-            # BASELINE config 4's storage on the same workload, same run (its own line: python bench.py --dtype fp8): 8-bit activations,
-            # weights and gradients on the block-scaled MFMA.  Parity unpinned by construction; it is not `value`.
-            e8 = Engine(adabn=args.adabn, dtype="fp8", dp_emg=args.dp_emg, device=dev, seed=1000)
-            e8.init_parameters(seed=42)
-            e8.workspace(N)
+            try:
+                # BASELINE config 4's storage on the same workload, same run (its own line: python bench.py --dtype fp8): 8-bit activations,
+                # weights and gradients on the block-scaled MFMA.  Parity unpinned by construction; it is not `value`.
+                e8 = Engine(adabn=args.adabn, dtype="fp8", dp_emg=args.dp_emg, device=dev, seed=1000)
+                e8.init_parameters(seed=42)
+                e8.workspace(N)
 
-            def step8(i):
-                x = e8.gather(table, emg_rand, perms[i], 1)
-                z = e8.encoder_forward(x, training=True)
-                o, _, _ = e8.head(z, labels, 1, want_grad=True)
-                e8.encoder_backward(x)
-                e8.adam_step(params)
-                return o
-            for i in range(4):
-                step8(i)
-            torch.cuda.synchronize(dev)
-            k8 = max(5, args.steps // 2)
-            t8 = time.perf_counter()
-            for i in range(k8):
-                o8 = step8(args.warmup + (i % args.steps))
-            torch.cuda.synchronize(dev)
-            el8 = time.perf_counter() - t8
-            rec["config4_fp8"] = dict(ms_per_step=1e3 * el8 / k8, value=N * k8 / el8, unit="windows/s", steps=k8, loss=float(o8[0]),
-                                      note="same workload with 8-bit storage + MX MFMA (CP_FP8), parity unpinned by construction; full line: bench.py --dtype fp8")
-            del e8
+                def step8(i):
+                    x = e8.gather(table, emg_rand, perms[i], 1)
+                    z = e8.encoder_forward(x, training=True)
+                    o, _, _ = e8.head(z, labels, 1, want_grad=True)
+                    e8.encoder_backward(x)
+                    e8.adam_step(params)
+                    return o
+                for i in range(4):
+                    step8(i)
+                torch.cuda.synchronize(dev)
+                k8 = max(5, args.steps // 2)
+                t8 = time.perf_counter()
+                for i in range(k8):
+                    o8 = step8(args.warmup + (i % args.steps))
+                torch.cuda.synchronize(dev)
+                el8 = time.perf_counter() - t8
+                rec["config4_fp8"] = dict(ms_per_step=1e3 * el8 / k8, value=N * k8 / el8, unit="windows/s", steps=k8, loss=float(o8[0]),
+                                          note="same workload with 8-bit storage + MX MFMA (CP_FP8), parity unpinned by construction; full line: bench.py --dtype fp8")
+                del e8
+            except Exception as ex:                       # a side record: never at the cost of the line
+                rec["config4_fp8"] = dict(error=f"{type(ex).__name__}: {ex}")
         if world == 1 and not rehearse and args.class_encoder == "onehot" and not args.main_only:
-            rec["small_batch"] = small_batch_record(dev, args.dtype)
-            if "cpu_baseline" in rec and "b8" in rec["cpu_baseline"]:
-                rec["small_batch"]["b8"]["over_cpu_b8"] = rec["small_batch"]["b8"]["windows_per_s"] / rec["cpu_baseline"]["b8"]["value"]
+            try:
+                rec["small_batch"] = small_batch_record(dev, args.dtype)
+                if "cpu_baseline" in rec and "b8" in rec["cpu_baseline"]:
+                    rec["small_batch"]["b8"]["over_cpu_b8"] = rec["small_batch"]["b8"]["windows_per_s"] / rec["cpu_baseline"]["b8"]["value"]
+            except Exception as ex:
+                rec["small_batch"] = dict(error=f"{type(ex).__name__}: {ex}")
         print(json.dumps(rec), flush=True)
     if use_dist:
         dist.destroy_process_group()
