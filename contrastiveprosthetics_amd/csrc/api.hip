@@ -726,7 +726,7 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     const int tiles_m = (int)((N + SM_BM - 1) / SM_BM);
-    const bool ks = sm_ksplit<T>(N);                   // f32, few row tiles: 64-feature tiles with the contraction split over wave pairs
+    const bool ks = sm_ksplit<T>(N);                   // few row tiles: 64-feature tiles with the contraction split over wave pairs
     {
         ProfScope ps(CP_K_PREP, st);
         SmPrepBatch cb{};
@@ -777,12 +777,8 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
         a.bn_in = bn_of(Lp); a.smod = kLayerC[Lp]; a.N = N; a.K = K;
         if (drop && Lp >= 5) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         ProfScope ps(K == 512 ? CP_K_FC_FWD_WS : CP_K_FC_FWD, st);
-        if constexpr (sizeof(T) == 4) {
-            if (ks) hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0, true>), dim3(tiles_m * (512 / SmTile<true>::BN)), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0>), dim3(tiles_m * (512 / SM_BN)), dim3(256), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0>), dim3(tiles_m * (512 / SM_BN)), dim3(256), 0, st, a);
-        }
+        if (ks) hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0, true>), dim3(tiles_m * (512 / SmTile<true>::BN)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((sm_fc_fwd_kernel<T, 0>), dim3(tiles_m * (512 / SM_BN)), dim3(256), 0, st, a);
         CKL("sm_fc_fwd_kernel");
     }
     {
@@ -842,12 +838,8 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
         a.p_valid = CP_D_E; a.N = N; a.K = 512; a.smod = 512; a.wmode = 0; a.n_dgrad = tiles_m * (512 / bn_tile);
         if (drop) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         ProfScope ps(CP_K_PROJ_BWD, st);
-        if constexpr (sizeof(T) == 4) {
-            if (ks) hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
-        }
+        if (ks) hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((sm_fc_bwd_kernel<T, true>), dim3(a.n_dgrad + 8 * splits), dim3(256), 0, st, a);
         CKL("sm_fc_bwd_kernel<proj>");
     }
     for (int L = 8; L >= 2; --L) {
@@ -863,12 +855,8 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
         a.N = N; a.K = K; a.smod = kLayerC[Lp]; a.wmode = i == 0 ? 1 : 0; a.n_dgrad = tiles_m * (K / bn_tile);
         if (drop && Lp >= 5) { a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c); }
         ProfScope ps(CP_K_FC_DGRAD, st);
-        if constexpr (sizeof(T) == 4) {
-            if (ks) hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false, true>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
-        }
+        if (ks) hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false, true>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((sm_fc_bwd_kernel<T, false>), dim3(a.n_dgrad + 8 * (K / 64) * splits), dim3(256), 0, st, a);
         CKL("sm_fc_bwd_kernel");
         cur ^= 1;
     }

@@ -113,9 +113,9 @@ template <typename T> struct SmNsub { static constexpr int v = sizeof(T) == 2 ? 
 // measured, of a 17 us launch), so the contraction is split over wave PAIRS: 64-feature tiles, wave w = feature group w & 1, k half
 // w >> 1 of every 32-deep sub-tile; the two partial tiles meet in LDS in the epilogue (0.45 -> 0.37 ms per step at 8 groups).
 // bf16, and f32 from 25 groups up: 128-feature tiles, no split (at 32 groups the split's 328 workgroups need a second round: 0.55 -> 0.60 ms).
-// (the split doubles the workgroups: it is used while they still fit one round of the 256 CUs -- sm_ksplit() -- f32 only)
+// (the split doubles the workgroups: it is used while they still fit one round of the 256 CUs -- sm_ksplit())
 template <bool KS> struct SmTile { static constexpr int BN = KS ? 64 : SM_BN; static constexpr bool KSPLIT = KS; };
-template <typename T> static inline bool sm_ksplit(int64_t n_windows) { return sizeof(T) == 4 && (n_windows + SM_BM - 1) / SM_BM * 8 <= 256; }
+template <typename T> static inline bool sm_ksplit(int64_t n_windows) { return (n_windows + SM_BM - 1) / SM_BM * 8 <= 256; }
 // NT: acc += A'[32 rows][K] x W[BN rows][K]^T for the wave's 32 x 32 piece (W rows wrow .. wrow+31).  loadA(sub) / loadW(sub, i) return the
 // thread's 16-byte chunk (row tid >> 3 [+ 32 i], chunk tid & 7) of sub-tile `sub`; xformA(raw, sub) turns the raw A chunk into the operand.
 template <typename T, int BN, typename RawA, bool KSPLIT = false, typename FA, typename XA, typename FW, typename Mid>
@@ -204,7 +204,8 @@ __device__ __forceinline__ void sm_nt_loop(f32x16& acc, unsigned char* smem, int
 template <typename T, int BN> struct SmNT {
     static constexpr int LOOP_BYTES = SmNsub<T>::v * (SM_BM * 128 + BN * 128);
     static constexpr int C_PITCH = BN * (int)sizeof(T) + 16, C_BYTES = SM_BM * C_PITCH, RED_BYTES = 2 * 256 * DT<T>::EPC * 4;
-    static constexpr int EPI_BYTES = 2 * C_BYTES + RED_BYTES;            // (two images: the k halves of a split contraction)
+    static constexpr int F_PITCH = BN * 4 + 16, F_BYTES = SM_BM * F_PITCH;   // an f32 image of the tile: one per k half of a split contraction
+    static constexpr int EPI_BYTES = 2 * F_BYTES + RED_BYTES;
     static constexpr int BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
 };
 
@@ -314,15 +315,18 @@ struct SmFwdArgs {
 
 // epilogue shared by the forward and the data-gradient role: the 32 x BN tile (already in the LDS image Cs, T) leaves as 16-byte row
 // segments; per column sums of v and of v * w (w = v itself, or the matching element of a second tensor) -> out_partials
-template <typename T, int BN, typename FV>
+template <typename T, int BN, bool KS = false, typename FV>
 __device__ __forceinline__ void sm_store_tile(unsigned char* smem, void* Cout, int64_t ldc, int64_t m0, int64_t N, int c0, float* out_partials,
                                               int64_t tile_m, int out_ld, long long* out_acc, int acc_shift, FV&& per_chunk) {
+    // The tile sits in LDS as ONE image in T (row pitch C_PITCH) or, KS, as TWO f32 images of partial sums (the k halves, row pitch
+    // F_PITCH, F_BYTES apart) that are added here.  per_chunk(v[EPC], m, column, s1, s2) finishes the values in f32 (bias, ReLU,
+    // dropout mask, ...) and accumulates the two column sums; what it leaves in v is rounded to T and stored.
     using D = DT<T>;
-    constexpr int EPC = D::EPC, C_PITCH = SmNT<T, BN>::C_PITCH, C_BYTES = SmNT<T, BN>::C_BYTES;
+    using G = SmNT<T, BN>;
+    constexpr int EPC = D::EPC, C_PITCH = G::C_PITCH, F_PITCH = G::F_PITCH, F_BYTES = G::F_BYTES;
     constexpr int CPR = BN / EPC, RPP = 256 / CPR;
     const int tid = threadIdx.x;
-    unsigned char* Cs = smem;
-    float* red = (float*)(smem + 2 * C_BYTES);
+    float* red = (float*)(smem + 2 * F_BYTES);
     const int cc = tid % CPR, rr = tid / CPR;
     float s1[EPC], s2[EPC];
 #pragma unroll
@@ -333,9 +337,19 @@ __device__ __forceinline__ void sm_store_tile(unsigned char* smem, void* Cout, i
         const int row = rr + p * RPP;
         const int64_t m = m0 + row;
         if (m < N) {
-            uint4 c = *(const uint4*)(Cs + row * C_PITCH + cc * 16);
-            per_chunk(c, m, c0 + cc * EPC, s1, s2);
-            *(uint4*)(Cg + m * ldc + c0 + cc * EPC) = c;
+            float v[EPC];
+            if constexpr (KS) {
+#pragma unroll
+                for (int q = 0; q < EPC / 4; ++q) {
+                    const float4 x = *(const float4*)(smem + row * F_PITCH + (cc * EPC + 4 * q) * 4);
+                    const float4 y = *(const float4*)(smem + F_BYTES + row * F_PITCH + (cc * EPC + 4 * q) * 4);
+                    v[4 * q] = x.x + y.x; v[4 * q + 1] = x.y + y.y; v[4 * q + 2] = x.z + y.z; v[4 * q + 3] = x.w + y.w;
+                }
+            } else {
+                D::unpack(*(const uint4*)(smem + row * C_PITCH + cc * 16), v);
+            }
+            per_chunk(v, m, c0 + cc * EPC, s1, s2);
+            *(uint4*)(Cg + m * ldc + c0 + cc * EPC) = D::pack(v);
         }
     }
 #pragma unroll
@@ -359,7 +373,6 @@ __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
     using D = DT<T>;
     constexpr int EPC = D::EPC, BK = D::BK, BM = SM_BM, BN = MODE == 0 ? SmTile<KS>::BN : 32;
     constexpr bool KSPLIT = MODE == 0 && KS;
-    static_assert(!KS || sizeof(T) == 4, "the k split is the f32 form");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SmNT<T, BN>::BYTES];
     __shared__ __attribute__((aligned(16))) float s_in[512], t_in[512];
 
@@ -423,13 +436,13 @@ __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
         }
         return;
     } else {
-        constexpr int C_PITCH = SmNT<T, BN>::C_PITCH, C_BYTES = SmNT<T, BN>::C_BYTES;
+        constexpr int C_PITCH = SmNT<T, BN>::C_PITCH, F_PITCH = SmNT<T, BN>::F_PITCH, F_BYTES = SmNT<T, BN>::F_BYTES;
         if constexpr (KSPLIT) {
-            // raw partial sums of this wave's k half into image (wave >> 1); bias, ReLU and the statistics when the halves meet below
+            // raw f32 partial sums of this wave's k half into image (wave >> 1); bias, ReLU and the statistics when the halves meet below
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int fl = (wave & 1) * 32 + 8 * q + 4 * h;
-                *(float4*)(smem + (wave >> 1) * C_BYTES + r * C_PITCH + fl * 4) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                *(float4*)(smem + (wave >> 1) * F_BYTES + r * F_PITCH + fl * 4) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
             }
         } else {
 #pragma unroll
@@ -444,15 +457,10 @@ __global__ __launch_bounds__(256) void sm_fc_fwd_kernel(SmFwdArgs a) {
             }
         }
         __syncthreads();
-        sm_store_tile<T, BN>(smem, a.C, 512, m0, a.N, f0, nullptr, tile_m, 512, a.out_acc, SM_ACT_SHIFT, [&](uint4& c, int64_t m, int f, float* s1, float* s2) {
-            float v[EPC];
-            D::unpack(c, v);
+        sm_store_tile<T, BN, KSPLIT>(smem, a.C, 512, m0, a.N, f0, nullptr, tile_m, 512, a.out_acc, SM_ACT_SHIFT, [&](float* v, int64_t, int f, float* s1, float* s2) {
             if constexpr (KSPLIT) {
-                const float4 o = *(const float4*)(smem + C_BYTES + (int)(m - m0) * C_PITCH + (f - f0) * 4);
-                const float4 b = *(const float4*)(a.bias + f);
-                v[0] = fmaxf(v[0] + o.x + b.x, 0.f); v[1] = fmaxf(v[1] + o.y + b.y, 0.f);
-                v[2] = fmaxf(v[2] + o.z + b.z, 0.f); v[3] = fmaxf(v[3] + o.w + b.w, 0.f);
-                c = D::pack(v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = D::round(fmaxf(v[e] + a.bias[f + e], 0.f));
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
@@ -524,7 +532,6 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
     using D = DT<T>;
     constexpr int EPC = D::EPC, BK = D::BK, BM = SM_BM, BN = SmTile<KS>::BN;
     constexpr bool KSPLIT = KS;
-    static_assert(!KS || sizeof(T) == 4, "the k split is the f32 form");
     constexpr int KC = PROJ ? 64 : 512;                    // contraction of the data gradient = width of Gin
     constexpr int LDS_BYTES = SmNT<T, BN>::BYTES > SmTN<T>::BYTES ? SmNT<T, BN>::BYTES : SmTN<T>::BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -589,23 +596,23 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
             },
             [&](int sub, int i) -> uint4 { return *(const uint4*)(Wg + (int64_t)(k0o + sr + 32 * i) * KC + sub * BK + sc * EPC); },
             KSPLIT ? (wave & 1) * 32 : wave * 32, true, prologue);
-        constexpr int C_PITCH = SmNT<T, BN>::C_PITCH, C_BYTES = SmNT<T, BN>::C_BYTES;
+        constexpr int C_PITCH = SmNT<T, BN>::C_PITCH, F_PITCH = SmNT<T, BN>::F_PITCH, F_BYTES = SmNT<T, BN>::F_BYTES;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int fl = (KSPLIT ? (wave & 1) : wave) * 32 + 8 * q + 4 * h;
-            unsigned char* dst = smem + (KSPLIT ? (wave >> 1) * C_BYTES : 0) + r * C_PITCH + fl * (int)sizeof(T);      // (KSPLIT: image = k half)
-            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2bf(acc[4 * q], acc[4 * q + 1]), pack2bf(acc[4 * q + 2], acc[4 * q + 3]));
-            else *(float4*)dst = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            if constexpr (KSPLIT) {                         // raw f32 partial sums, image = k half
+                const int fl = (wave & 1) * 32 + 8 * q + 4 * h;
+                *(float4*)(smem + (wave >> 1) * F_BYTES + r * F_PITCH + fl * 4) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            } else {
+                const int fl = wave * 32 + 8 * q + 4 * h;
+                unsigned char* dst = smem + r * C_PITCH + fl * (int)sizeof(T);
+                if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2bf(acc[4 * q], acc[4 * q + 1]), pack2bf(acc[4 * q + 2], acc[4 * q + 3]));
+                else *(float4*)dst = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
         }
         __syncthreads();
         const T* Rpg = (const T*)a.Rp;
-        sm_store_tile<T, BN>(smem, a.Gout, a.K, m0, a.N, k0o, a.out_partials, tile_m, a.K, a.out_acc, SM_GRAD_SHIFT, [&](uint4& c, int64_t m, int k, float* s1, float* s2) {
-            float v[EPC], rv[EPC];
-            D::unpack(c, v);
-            if constexpr (KSPLIT) {                         // the other k half of the product
-                const float4 o = *(const float4*)(smem + C_BYTES + (int)(m - m0) * C_PITCH + (k - k0o) * 4);
-                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-            }
+        sm_store_tile<T, BN, KSPLIT>(smem, a.Gout, a.K, m0, a.N, k0o, a.out_partials, tile_m, a.K, a.out_acc, SM_GRAD_SHIFT, [&](float* v, int64_t m, int k, float* s1, float* s2) {
+            float rv[EPC];
             D::unpack(*(const uint4*)(Rpg + m * a.K + k), rv);
             if (a.dp_thresh != 0) {
 #pragma unroll
@@ -614,9 +621,6 @@ __global__ __launch_bounds__(256) void sm_fc_bwd_kernel(SmBwdArgs a) {
                     v[e] *= dropout_scale(pr, 0, a.dp_thresh, a.dp_inv_keep);
                     v[e + 1] *= dropout_scale(pr, 1, a.dp_thresh, a.dp_inv_keep);
                 }
-                c = D::pack(v);
-            } else if constexpr (KSPLIT) {
-                c = D::pack(v);
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
