@@ -13,9 +13,12 @@
 //   * the BatchNorm affine and the dropout mask are applied to the A operand while it is staged (no folded weight copy per layer,
 //     no dropout pass); backward: BatchNorm + ReLU backward of the layer is applied to the incoming gradient while it is staged, in
 //     the data-gradient AND in the weight-gradient role of the same launch (nothing is written in between);
-//   * weight gradients are whole sums over the batch per output tile (no split slabs, no reduction launch), written straight into
-//     the gradient buffer in the reference's layout.
-// Tiles are small (32 rows x 128 features; 64 x 64 for weight gradients) so that 328 rows still give 44 / 64 workgroups.
+//   * weight gradients: 64 x 64 tiles, whole-batch sums up to 256 rows, otherwise 2..8 row splits into slabs that ONE launch sums at the
+//     end of the backward pass (one split at 328 rows was tried: the tiles then walk all rows in a latency-bound loop, slower);
+//   * one weight-preparation launch per step (sm_prep_kernel: copies, transposes, conv2's images, the zeroed totals); the conv stage's
+//     BatchNorm totals are the same fixed-point atomics (conv_kernels.cuh: bn1 / acc_out);
+//   * up to 24 groups the NT launches split their contraction over wave pairs (SmTile<true>: 64-feature tiles).
+// Tiles are small (32 rows x 128 or 64 features; 64 x 64 for weight gradients) so that 328 rows still give 44 - 88 workgroups per role.
 // T = float (parity path: the same f32 MFMA chain as the large-batch kernels, different summation grouping) or bf16.
 // A grid barrier inside one persistent launch was priced first (guide, price list): 4-7 us per barrier against 1.5-2 us per launch
 // boundary -- the boundaries are cheaper, and a chain of launches cannot hang.
