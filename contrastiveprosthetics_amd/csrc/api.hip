@@ -737,7 +737,7 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
         cb.tr[CP_N_FC] = TransposeJob{p->last_w, base + w.wlast_t, CP_D_E, 512, 64, 0};
         cb.ntrans = CP_N_FC + 1;
         cb.conv2_w = p->conv2_w; cb.wc2_f = base + w.wc2_f; cb.wc2_d = base + w.wc2_d;
-        hipLaunchKernelGGL((sm_prep_kernel<T>), dim3(512, cb.njobs + 1 + cb.ntrans + 1), dim3(256), 0, st, cb);
+        hipLaunchKernelGGL((sm_prep_kernel<T>), dim3(SM_PREP_GX, cb.njobs + 1 + cb.ntrans + 1), dim3(256), 0, st, cb);
         CKL("prep kernels (small)");
     }
     // conv1 statistics and conv2: fixed-point totals like the fc stack's -- conv2's kernel finalises BatchNorm1 in its prologue, fc1's

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void sm_reduce_grads_kernel(SmReduceBatch b) {
 
 // this step's copies of the fc weights in the compute dtype, one launch: job j = {W f32 [F][K], out T [rows_out][K]}; mode 1 (fc1):
 // columns in the internal order k' = w*64 + c of the reference's k = c*12 + w.  grid (512, jobs).
-// ONE weight-preparation launch per step (grid (512, njobs + 1 + ntrans + 1)): the T copies of the fc weights and the projection
+// ONE weight-preparation launch per step (grid (SM_PREP_GX, njobs + 1 + ntrans + 1)): the T copies of the fc weights and the projection
 // (forward operands, fc1 in the internal column order), the step's BatchNorm accumulators zeroed, the transposed copies the backward
 // pass's data gradients read (they depend on the parameters only, so they can be made before the forward pass needs nothing of them),
 // and conv2's two tap-major weight images.  (Three launches until round 3: 20 us of a 300 us step.)
@@ -721,6 +721,10 @@ struct SmPrepBatch {
     TransposeJob tr[8]; int ntrans;
     const float* conv2_w; void* wc2_f; void* wc2_d;
 };
+// grid (128, jobs): a copy job's workgroups walk its rows with stride 128, a transpose job's its
+// 64 x 64 tiles (at most 96 per job: one each), conv2's images 48 workgroups' worth of elements.  (The first merged form launched
+// 512 x 18 workgroups, most of which returned at once: 13.6 us, more than the three launches' longest.)
+#define SM_PREP_GX 128
 template <typename T>
 __global__ __launch_bounds__(256) void sm_prep_kernel(SmPrepBatch b) {
     using D = DT<T>;
@@ -728,16 +732,15 @@ __global__ __launch_bounds__(256) void sm_prep_kernel(SmPrepBatch b) {
     const int y = blockIdx.y;
     if (y < b.njobs) {
         const SmCopyJob jb = b.job[y];
-        const int j = blockIdx.x;
-        if (j >= jb.rows_out) return;
-        for (int kp = threadIdx.x; kp < jb.K; kp += 256) {
-            const int k = jb.mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;
-            D::store((T*)jb.out + (int64_t)j * jb.K + kp, j < jb.F ? jb.W[(int64_t)j * jb.K + k] : 0.f);
-        }
+        for (int j = blockIdx.x; j < jb.rows_out; j += SM_PREP_GX)
+            for (int kp = threadIdx.x; kp < jb.K; kp += 256) {
+                const int k = jb.mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;
+                D::store((T*)jb.out + (int64_t)j * jb.K + kp, j < jb.F ? jb.W[(int64_t)j * jb.K + k] : 0.f);
+            }
     } else if (y == b.njobs) {                              // the step's BatchNorm accumulators (forward and backward) start at zero
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < b.nzero; i += gridDim.x * 256) b.zero[i] = 0;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < b.nzero; i += SM_PREP_GX * 256) b.zero[i] = 0;
     } else if (y <= b.njobs + b.ntrans) {
-        if (blockIdx.x < 128) transpose_w_job<T>(b.tr[y - b.njobs - 1], blockIdx.x, 128, tile);
+        transpose_w_job<T>(b.tr[y - b.njobs - 1], blockIdx.x, SM_PREP_GX, tile);
     } else {
         if (blockIdx.x < 48) prep_conv2_body<T>(b.conv2_w, (T*)b.wc2_f, (T*)b.wc2_d, blockIdx.x * 256 + threadIdx.x, 48 * 256);
     }
