@@ -39,13 +39,13 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}
 
 
 # profiler kind -> the ONE kernel it times, as rocprofv3 names it ({dyn} = the tile schedule, include/cpnative.h
-# cp_set_tile_schedule: "false" static, "true" dynamic).  The library has ONE kernel per kind since round 3 (the superseded
+# cp_config.tile_schedule: "false" static, "true" dynamic).  The library has ONE kernel per kind since round 3 (the superseded
 # variants moved to the tools-only build, csrc/variants.cuh).
 GEMM_KERNELS = {
     "bf16": {
         "fc_fwd_ws": "gemm_ws16_kernel",                      # weight-stationary forward, fc2..fc7 (K = 512), static schedule
         "fc_fwd": "gemm_ws16k_kernel",                        # weight-stationary with the k range split over wave pairs: fc1 (K = 768)
-        "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only under cp_debug_set_option "unfused_bn_bwd")
+        "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only under CP_OPT_UNFUSED_BN_BWD)
         "fc_dgrad_bn": "gemm_wsd16_kernel<0>",                # + BN/ReLU backward of the layer below against the saved activation
         "fc_dgrad_stats": "gemm_wsd16_kernel<1>",             # behind a dropout: mask + BN-backward sums against the saved activation
         "fc_wgrad": "gemm_tn256_kernel",
@@ -89,7 +89,7 @@ def gemm_model(kind: str, n: int, dtype: str, dropout: bool):
     elif kind == "fc_fwd":          # fc1 (K = 768) on its own kernel, or every layer without the weight-stationary kernels
         layers, per = (range(0, 1) if ws else range(7)), lambda k: k + 512
     elif kind == "fc_dgrad":        # read g_y, write g_v (only with CPNATIVE_UNFUSED_BN_BWD: the plain persistent launch)
-        layers, per = range(0), lambda k: 512 + k          # (only under cp_debug_set_option "unfused_bn_bwd": never in this bench)
+        layers, per = range(0), lambda k: 512 + k          # (only under CP_OPT_UNFUSED_BN_BWD: never in this bench)
     elif kind == "fc_dgrad_bn":     # read g_y and the saved activation of the layer below, write its dL/d(pre-activation)
         lo = 1 if dtype == "fp8" else 0                       # (fp8: fc1's launch is its own kind)
         layers, per = (range(lo, 4) if dropout else range(lo, 7)), lambda k: 512 + 2 * k
@@ -415,7 +415,7 @@ def main():
         prefix = {"bf16": "r03", "fp8": "r03_fp8", "f32": "r03_f32"}[dt]
         dom = max(gemm_kinds, key=lambda k: prof.get(k, (0.0, 0))[0])
         ms, launches = prof[dom]
-        dyn = "true" if eng.lib.cp_get_tile_schedule() else "false"
+        dyn = "true" if eng.tile_schedule else "false"
         kname = gemm_symbol(dom, dyn, dt)
         # counter evidence from the COMMITTED profiles of this same command on the builder's box (tools/profile_round.sh): not
         # measured in this run, and labelled so
@@ -479,7 +479,7 @@ def main():
                                loss={"gather": "global negatives (class->EMG direction over the gathered z)",
                                      "reduce": "global negatives (partial sums + two 64-float all-reduces, no z all-gather)",
                                      "off": "reference per-group loss"}[gn],
-                               tile_schedule="dynamic" if eng.lib.cp_get_tile_schedule() else "static"),
+                               tile_schedule="dynamic" if eng.tile_schedule else "static"),
                    loss=loss, train_acc=correct / N, roofline=roof,
                    steps_spread=dict(min_ms=step_ms[0], median_ms=step_ms[len(step_ms) // 2], max_ms=step_ms[-1],
                                      note="per-step HIP events on the launch stream, rank 0"))

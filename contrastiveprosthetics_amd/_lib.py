@@ -33,12 +33,23 @@ class cp_bn_buffers(C.Structure):
     _fields_ = [("running_mean", _fp * CP_N_BN), ("running_var", _fp * CP_N_BN)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)     # cp_allreduce_fn
+
+# cp_config.options bits (include/cpnative.h CP_OPT_*): test / measurement switches of ONE call, 0 in production
+OPTIONS = {"unfused_bn_bwd": 1, "unpaired_wgrad": 2, "fp8_bridge": 4, "no_small": 8, "fp8_head_f32": 16, "finalize_launches": 32}
+CP_TILES_STATIC, CP_TILES_DYNAMIC = 0, 1
+
+
 class cp_config(C.Structure):
+    """Everything a call depends on besides its tensors: the library keeps no per-process state for the training path."""
     _fields_ = [
         ("n_windows", C.c_int64), ("dtype", C.c_int32), ("adabn", C.c_int32),
         ("training", C.c_int32), ("step_state_lo", C.c_uint32),
         ("dp_emg", C.c_float), ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("step_state_hi", C.c_uint32),
         ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("options", C.c_uint32), ("tile_schedule", C.c_int32),
+        ("stats_allreduce", C.c_void_p), ("stats_user", C.c_void_p), ("stats_world", C.c_int32), ("reserved0", C.c_int32),
+        ("grad_tap", C.c_void_p), ("grad_tap_bytes", C.c_size_t),
     ]
 
 
@@ -57,7 +68,6 @@ class cp_glove_params(C.Structure):
 SYMBOLS = {
     "cp_version": (C.c_int, []),
     "cp_last_error": (C.c_char_p, []),
-    "cp_debug_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
     "cp_has_variants": (C.c_int, []),
     "cp_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_float]),
     "cp_gather_groups": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, C.c_int32, _fp, _fp]),
@@ -71,7 +81,6 @@ SYMBOLS = {
     "cp_global_negatives_h": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp]),
     "cp_head_gneg": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t,
                                _fp, _fp, _fp, _P(cp_params), _fp, _fp]),
-    "cp_set_stats_allreduce": (C.c_int, [_fp, _fp, C.c_int32]),
     "cp_encoder_backward": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, _P(cp_params), _fp]),
     "cp_encoder_backward_ev": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, _P(cp_params), _fp, _fp]),
     "cp_vote": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp]),
@@ -94,20 +103,15 @@ SYMBOLS = {
     "cp_l2_adam_step_graph": (C.c_int, [_fp, _fp, _fp, _fp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int32),
                                         C.c_int32, _P(cp_adam_hyper), _fp, _fp, _fp, _fp]),
     "cp_debug_hog": (C.c_int, [C.c_int32, C.c_int32, _fp]),
-    "cp_set_tile_schedule": (C.c_int, [C.c_int32]),
-    "cp_get_tile_schedule": (C.c_int, []),
     "cp_profile_enable": (C.c_int, [C.c_uint64, C.c_int32]),
     "cp_profile_disable": (C.c_int, []),
     "cp_profile_resume": (C.c_int, []),
     "cp_profile_summary": (C.c_int, [C.c_int32, _P(C.c_double), _P(C.c_int64)]),
     "cp_debug_activation": (C.c_int, [_P(cp_config), _P(cp_params), _fp, _fp, C.c_size_t, C.c_int32, _fp, _fp]),
-    "cp_debug_set_grad_tap": (C.c_int, [_fp, C.c_size_t]),
     "cp_debug_bn_stats": (C.c_int, [_P(cp_config), _fp, C.c_size_t, C.c_int32, _fp, _fp]),
     "cp_debug_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp,
                                 C.c_int32, _fp]),
 }
-
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)     # cp_allreduce_fn
 
 KERNEL_KINDS = ["gather", "prep", "conv1_fwd", "bn_finalize", "conv2_fwd", "fold", "fc_fwd", "dropout", "proj_fwd",
                 "head", "proj_bwd", "bn_bwd", "fc_wgrad", "reduce_slabs", "fc_dgrad", "conv2_wgrad", "conv2_dgrad",
@@ -134,7 +138,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.cp_version() < 100:
+    if lib.cp_version() < 110:
         raise CpNativeError("libcpnative.so is older than this binding")
     _lib = lib
     return lib

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cctype>
+#include <mutex>
 
 #include "../../include/cpnative.h"
 #include "common.cuh"
@@ -45,24 +46,11 @@ static int fail(int code, const char* what) {
 extern "C" int cp_version(void) { return CP_VERSION; }
 
 // ---------------------------------------------------------------------------------------
-// process-wide switches (common.cuh, CpOptions): set explicitly, never read from the environment on a launch path
+// No process-wide switches: a call's options, tile schedule, synchronised-BatchNorm hook and gradient tap travel in its
+// cp_config (include/cpnative.h).  Only the tools-only build keeps a global (common.cuh, CpVariantOptions): one switch per
+// superseded kernel, seeded ONCE from $CPNATIVE_<NAME> when that library is loaded (tools/ab_env.sh and friends).
 // ---------------------------------------------------------------------------------------
-struct OptName { const char* name; int CpOptions::*field; };
-static const OptName kOptNames[] = {
-    {"unfused_bn_bwd", &CpOptions::unfused_bn_bwd}, {"unpaired_wgrad", &CpOptions::unpaired_wgrad}, {"fp8_bridge", &CpOptions::fp8_bridge},
-    {"no_small", &CpOptions::no_small}, {"fp8_head_f32", &CpOptions::fp8_head_f32},
-#ifdef CP_VARIANTS
-    {"no_ws", &CpOptions::no_ws}, {"no_wsk", &CpOptions::no_wsk}, {"no_wsd", &CpOptions::no_wsd}, {"no_wsd_st", &CpOptions::no_wsd_st},
-    {"staged_r_epilogue", &CpOptions::staged_r_epilogue}, {"ws32", &CpOptions::ws32}, {"wsd32", &CpOptions::wsd32}, {"tn_w4", &CpOptions::tn_w4},
-    {"tn16", &CpOptions::tn16}, {"materialize_u8", &CpOptions::materialize_u8}, {"no_proj_fused", &CpOptions::no_proj_fused},
-#endif
-};
-extern "C" int cp_debug_set_option(const char* name, int32_t value) {
-    if (name)
-        for (const OptName& o : kOptNames)
-            if (!strcmp(name, o.name)) { g_opt.*(o.field) = value; return 0; }
-    return fail(CP_ERR_ARG, "cp_debug_set_option: unknown option (the superseded kernels live in the tools-only build, make -C csrc variants)");
-}
+static inline bool opt(const cp_config* c, uint32_t bit) { return (c->options & bit) != 0; }
 extern "C" int cp_has_variants(void) {
 #ifdef CP_VARIANTS
     return 1;
@@ -71,50 +59,30 @@ extern "C" int cp_has_variants(void) {
 #endif
 }
 #ifdef CP_VARIANTS
-// tools-only build: $CPNATIVE_<NAME> seeds a switch ONCE, when the library is loaded (tools/ab_env.sh and friends)
-static int seed_options_from_env() {
-    for (const OptName& o : kOptNames) {
+struct VarName { const char* name; int CpVariantOptions::*field; };
+static const VarName kVarNames[] = {
+    {"no_ws", &CpVariantOptions::no_ws}, {"no_wsk", &CpVariantOptions::no_wsk}, {"no_wsd", &CpVariantOptions::no_wsd},
+    {"no_wsd_st", &CpVariantOptions::no_wsd_st}, {"staged_r_epilogue", &CpVariantOptions::staged_r_epilogue},
+    {"ws32", &CpVariantOptions::ws32}, {"wsd32", &CpVariantOptions::wsd32}, {"tn_w4", &CpVariantOptions::tn_w4},
+    {"tn16", &CpVariantOptions::tn16}, {"materialize_u8", &CpVariantOptions::materialize_u8},
+    {"no_proj_fused", &CpVariantOptions::no_proj_fused},
+};
+static int seed_variants_from_env() {
+    for (const VarName& o : kVarNames) {
         char env[64] = "CPNATIVE_";
         size_t n = strlen(env);
         for (const char* c = o.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper(*c);
         env[n] = 0;
-        if (getenv(env)) g_opt.*(o.field) = 1;
+        if (getenv(env)) g_var.*(o.field) = 1;
     }
     return 0;
 }
-static const int g_opt_seeded = seed_options_from_env();
+static const int g_var_seeded = seed_variants_from_env();
 #endif
 extern "C" const char* cp_last_error(void) { return g_err; }
 
-// tile schedule of the persistent fc GEMM kernels (cpnative.h); -1 = not chosen yet: $CPNATIVE_TILE_SCHEDULE or static
-static int g_tile_schedule = -1;
-static int tile_schedule() {
-    if (g_tile_schedule < 0) {
-        const char* e = getenv("CPNATIVE_TILE_SCHEDULE");
-        g_tile_schedule = (e && !strcmp(e, "dynamic")) ? CP_TILES_DYNAMIC : CP_TILES_STATIC;
-    }
-    return g_tile_schedule;
-}
-extern "C" int cp_set_tile_schedule(int32_t mode) {
-    if (mode != CP_TILES_STATIC && mode != CP_TILES_DYNAMIC) return fail(CP_ERR_ARG, "cp_set_tile_schedule: mode");
-    g_tile_schedule = mode;
-    return 0;
-}
-extern "C" int cp_get_tile_schedule(void) { return tile_schedule(); }
-
-// ---------------------------------------------------------------------------------------
-// synchronised BatchNorm: the caller's sum over ranks of one row of statistics (cpnative.h)
-// ---------------------------------------------------------------------------------------
-static cp_allreduce_fn g_sync_fn = nullptr;
-static void* g_sync_user = nullptr;
-static int g_sync_world = 1;
-extern "C" int cp_set_stats_allreduce(cp_allreduce_fn fn, void* user, int32_t world) {
-    if (fn && world < 1) return fail(CP_ERR_ARG, "cp_set_stats_allreduce: world");
-    g_sync_fn = fn;
-    g_sync_user = user;
-    g_sync_world = fn ? world : 1;
-    return 0;
-}
+// tile schedule of the persistent fc GEMM kernels: cp_config.tile_schedule (cpnative.h)
+static inline bool dyn_tiles(const cp_config* c) { return c->tile_schedule == CP_TILES_DYNAMIC; }
 
 // ---------------------------------------------------------------------------------------
 // optional per-kernel-kind timing with HIP events recorded on the launch stream
@@ -301,6 +269,11 @@ static int check_cfg(const cp_config* c, void* ws, size_t ws_bytes, WS* out) {
     if (c->n_windows <= 0 || c->n_windows % CP_TASKS != 0) return fail(CP_ERR_ARG, "n_windows must be a positive multiple of 41");
     if (c->dtype != CP_F32 && c->dtype != CP_BF16 && c->dtype != CP_FP8) return fail(CP_ERR_ARG, "dtype");
     if (c->dp_emg < 0.f || c->dp_emg >= 1.f) return fail(CP_ERR_ARG, "dp_emg");
+    if (c->tile_schedule != CP_TILES_STATIC && c->tile_schedule != CP_TILES_DYNAMIC) return fail(CP_ERR_ARG, "tile_schedule");
+    if (c->stats_allreduce && c->stats_world < 1) return fail(CP_ERR_ARG, "stats_world");
+    // 32-bit byte offsets into an [n_windows][768] 16-bit tensor (the weight-stationary kernels' buffer loads) and the dropout hash's
+    // 32-bit element index: 2,795,000 windows = 68,000 groups per call (the 288 GB of HBM hold fewer in f32 anyway)
+    if ((uint64_t)c->n_windows * 768 * 2 >= 0xFFF00000ull) return fail(CP_ERR_ARG, "n_windows * 1536 must stay below 2^32 (32-bit buffer offsets)");
     *out = carve(c->n_windows, c->dtype, c->dp_emg);
     if (out->total > ws_bytes) return fail(CP_ERR_WORKSPACE, "workspace too small");
     if (((uintptr_t)ws & 255) != 0) return fail(CP_ERR_ARG, "workspace must be 256-byte aligned");
@@ -349,19 +322,19 @@ template <typename T> static inline int fc_bm() { return sizeof(T) == 2 ? 256 : 
 // BN-backward sums come from the weight gradient) run the persistent kernel (gemm_nt256p.cuh).
 // *stat_rows = number of partial rows of column sums the launch wrote.
 template <typename T, int EPI>
-static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int* stat_rows = nullptr) {
+static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int* stat_rows = nullptr, bool dyn_schedule = false) {
     if (stat_rows) *stat_rows = (int)((a.M + fc_bm<T>() - 1) / fc_bm<T>());
     if constexpr (sizeof(T) == 2) {
 #ifdef CP_VARIANTS
         // tools-only build: dbg bits (cp_debug_gemm) and the options pick superseded kernels -- dbg 64 / 128 force the dynamic /
         // static schedule, 256 / no_ws the tile-staged kernels, 16 / staged_r_epilogue the one-tile kernel with its LDS-staged epilogue
-        const bool dyn = (a.dbg & 64) ? true : (a.dbg & 128) ? false : tile_schedule() == CP_TILES_DYNAMIC;
-        const bool ws_ok = !dyn && !(a.dbg & (16 | 256)) && !g_opt.no_ws;
-        const bool wsk_ok = ws_ok && !g_opt.no_wsk;
-        const bool wsd_ok = ws_ok && !g_opt.no_wsd && (a.coef != nullptr || !g_opt.no_wsd_st);
-        const bool staged = (a.dbg & 16) || g_opt.staged_r_epilogue;
+        const bool dyn = (a.dbg & 64) ? true : (a.dbg & 128) ? false : dyn_schedule;
+        const bool ws_ok = !dyn && !(a.dbg & (16 | 256)) && !g_var.no_ws;
+        const bool wsk_ok = ws_ok && !g_var.no_wsk;
+        const bool wsd_ok = ws_ok && !g_var.no_wsd && (a.coef != nullptr || !g_var.no_wsd_st);
+        const bool staged = (a.dbg & 16) || g_var.staged_r_epilogue;
 #else
-        const bool dyn = tile_schedule() == CP_TILES_DYNAMIC;
+        const bool dyn = dyn_schedule;
         const bool ws_ok = !dyn, wsk_ok = !dyn, wsd_ok = !dyn;
 #endif
         // a process that has the GPU to itself (static schedule): the weight-stationary kernels (gemm_ws.cuh) -- K = 512 forward,
@@ -413,15 +386,16 @@ struct PreReduce {
 // Synchronised BatchNorm: fold `nrows` partial rows of `width` floats into ONE row (this rank's sums, kept in ws.sync_loc),
 // copy it, and have the caller's hook sum the copy over the ranks in place (ws.sync_glob).  Returns the global row;
 // *local = this rank's row.  Stream-ordered: the hook enqueues its collective behind `st` and makes `st` wait for it.
-static int sync_row(const float* pp, int nrows, int width, unsigned char* base, const WS& w, hipStream_t st, const float** glob,
-                    const float** local) {
+static int sync_row(const cp_config* c, const float* pp, int nrows, int width, unsigned char* base, const WS& w, hipStream_t st,
+                    const float** glob, const float** local, const int* unscale_exp = nullptr) {
     float* loc = (float*)(base + w.sync_loc);
     float* glo = (float*)(base + w.sync_glob);
     if (width > 2 * 768) return fail(CP_ERR_ARG, "sync_row width");
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(width)), dim3(FIN_THREADS), 0, st, pp, nrows, width, loc);
+    // (CP_FP8 forward: every rank keeps its own scale table, so the row goes into TRUE units before it meets the other ranks')
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(width)), dim3(FIN_THREADS), 0, st, pp, nrows, width, loc, unscale_exp, width / 2);
     CKL("colsum_finalize_kernel(sync)");
     CK(hipMemcpyAsync(glo, loc, (size_t)width * 4, hipMemcpyDeviceToDevice, st));
-    if (int e = g_sync_fn(g_sync_user, glo, width, st)) return fail(e, "the statistics all-reduce hook failed");
+    if (int e = c->stats_allreduce(c->stats_user, glo, width, st)) return fail(e, "the statistics all-reduce hook failed");
     *glob = glo;
     if (local) *local = loc;
     return 0;
@@ -445,10 +419,10 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         const int C = kLayerC[l];
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
         const float* pp = batch_stats ? pre(nrows, 2 * C) : partials;
-        if (batch_stats && g_sync_fn) {          // synchronised BatchNorm: statistics of the GLOBAL batch
-            if (int e = sync_row(pp, nrows, 2 * C, base, w, st, &pp, nullptr)) return e;
+        if (batch_stats && c->stats_allreduce) {          // synchronised BatchNorm: statistics of the GLOBAL batch
+            if (int e = sync_row(c, pp, nrows, 2 * C, base, w, st, &pp, nullptr)) return e;
             nrows = 1;
-            count *= g_sync_world;
+            count *= c->stats_world;
         }
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
                            have_running ? bn->running_mean[l] : nullptr, have_running ? bn->running_var[l] : nullptr, upd,
@@ -525,12 +499,12 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         {
             // (profiler kinds name ONE kernel each: K = 512 bf16 launches under the static schedule run gemm_ws_kernel)
 #ifdef CP_VARIANTS
-            const bool ws = sizeof(T) == 2 && K == WS_K && tile_schedule() != CP_TILES_DYNAMIC && !g_opt.no_ws;
+            const bool ws = sizeof(T) == 2 && K == WS_K && !dyn_tiles(c) && !g_var.no_ws;
 #else
-            const bool ws = sizeof(T) == 2 && K == WS_K && tile_schedule() != CP_TILES_DYNAMIC;
+            const bool ws = sizeof(T) == 2 && K == WS_K && !dyn_tiles(c);
 #endif
             ProfScope ps(ws ? CP_K_FC_FWD_WS : CP_K_FC_FWD, st);
-            CK((launch_fc_gemm<T, EPI_FWD>(a, st, &nrows)));
+            CK((launch_fc_gemm<T, EPI_FWD>(a, st, &nrows, dyn_tiles(c))));
         }
         if (int e = finalize(L, nrows, (double)N)) return e;
     }
@@ -543,7 +517,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         // gradient) form it from the saved activation while staging their operand -- both are bound by reading those 172 MB, and
         // the pass that materialised it moved 344 MB.  (tools-only build, option materialize_u8: the separate pass, as fc4..fc6 still have.)
 #ifdef CP_VARIANTS
-        const bool fused_u8 = drop && !g_opt.materialize_u8;
+        const bool fused_u8 = drop && !g_var.materialize_u8;
 #else
         const bool fused_u8 = drop;
 #endif
@@ -592,9 +566,8 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
     const bool batch_stats = c->training || c->adabn;
     const bool have_running = bn && bn->running_mean[0] && bn->running_var[0];
     if (!batch_stats && !have_running) return fail(CP_ERR_ARG, "eval with stock BN needs running statistics");
-    if (g_sync_fn) return fail(CP_ERR_ARG, "CP_FP8: synchronised BatchNorm is not wired into the 8-bit path");
-    if (tile_schedule() == CP_TILES_DYNAMIC) return fail(CP_ERR_ARG, "CP_FP8 runs the static tile schedule only");
-    if ((uint64_t)N * 768 >= 0xFFF00000ull) return fail(CP_ERR_ARG, "CP_FP8: n_windows * 768 must stay below 2^32 (32-bit buffer offsets)");
+    // (cp_config.tile_schedule is not consulted: the 8-bit kernels are weight-stationary, i.e. statically scheduled; a packed sweep
+    //  that asks for the dynamic schedule gets it on its 16/32-bit configurations)
     const int upd = (c->training && !c->adabn && have_running) ? 1 : 0;
     const bool drop = c->training && c->dp_emg > 0.f;
     float* partials = (float*)(base + w.partials);
@@ -605,6 +578,12 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
         const int C = kLayerC[l];
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
         const float* pp = batch_stats ? pre(nrows, 2 * C) : partials;
+        if (batch_stats && c->stats_allreduce) {          // synchronised BatchNorm: the row crosses the ranks in true units
+            if (int e = sync_row(c, pp, nrows, 2 * C, base, w, st, &pp, nullptr, unscale)) return e;
+            nrows = 1;
+            count *= c->stats_world;
+            unscale = nullptr;
+        }
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nrows, count, p->bn_g[l], p->bn_b[l],
                            have_running ? bn->running_mean[l] : nullptr, have_running ? bn->running_var[l] : nullptr, upd,
                            batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats(l), C, unscale);
@@ -709,9 +688,9 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
 // ---------------------------------------------------------------------------------------
 // small batches (csrc/small.cuh): N <= 64 groups, batch statistics, f32 or bf16
 // ---------------------------------------------------------------------------------------
-static unsigned char* g_grad_tap = nullptr;       // test aid, set by cp_debug_set_grad_tap (below)
 static bool use_small(const cp_config* c) {
-    return c->n_windows <= SM_MAX_WINDOWS && (c->training || c->adabn) && c->dtype != CP_FP8 && !g_sync_fn && !g_grad_tap && !g_opt.no_small;
+    return c->n_windows <= SM_MAX_WINDOWS && (c->training || c->adabn) && c->dtype != CP_FP8 && !c->stats_allreduce && !c->grad_tap &&
+           !opt(c, CP_OPT_NO_SMALL);
 }
 
 template <typename T>
@@ -869,12 +848,49 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
     return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gb[cur], gb[cur ^ 1], false, tiles_m);
 }
 
+// Which kernel path the last forward pass over a workspace took, keyed by the workspace address: the backward pass must take the same
+// one (the small-batch form and the large-batch form leave different things in the workspace) and learns here whether it is the first
+// backward over this forward (a repeat finds the small-batch form's fixed-point totals already summed and zeroes them first).  A
+// consistency check only -- nothing an engine computes depends on another engine's entries.
+enum { PATH_LARGE = 0, PATH_SMALL = 1, PATH_FP8 = 2 };
+struct FwdNote { const void* ws; int64_t n; int path; int backwards; uint64_t tick; };
+static FwdNote g_notes[64];
+static uint64_t g_note_tick = 0;
+static std::mutex g_notes_mu;
+static void note_forward(const void* ws, int64_t n, int path) {
+    std::lock_guard<std::mutex> lk(g_notes_mu);
+    FwdNote* slot = &g_notes[0];
+    for (FwdNote& f : g_notes) {
+        if (f.ws == ws) { slot = &f; break; }
+        if (f.tick < slot->tick) slot = &f;
+    }
+    *slot = FwdNote{ws, n, path, 0, ++g_note_tick};
+}
+// returns the number of backward passes already run over this forward, or -1 when the configurations disagree (-2: no forward on record)
+static int note_backward(const void* ws, int64_t n, int path) {
+    std::lock_guard<std::mutex> lk(g_notes_mu);
+    for (FwdNote& f : g_notes)
+        if (f.ws == ws && f.tick) {
+            if (f.n != n || f.path != path) return -1;
+            return f.backwards++;
+        }
+    return -2;
+}
+static int last_forward_path(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_notes_mu);
+    for (const FwdNote& f : g_notes)
+        if (f.ws == ws && f.tick) return f.path;
+    return -1;
+}
+static int forward_path(const cp_config* cfg) { return cfg->dtype == CP_FP8 ? PATH_FP8 : use_small(cfg) ? PATH_SMALL : PATH_LARGE; }
+
 extern "C" int cp_encoder_forward(const cp_config* cfg, const cp_params* p, const cp_bn_buffers* bn, const float* x,
                                   void* ws, size_t ws_bytes, float* z_out, void* stream) {
     WS w;
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !z_out) return fail(CP_ERR_ARG, "cp_encoder_forward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
+    note_forward(ws, cfg->n_windows, forward_path(cfg));
     if (cfg->dtype == CP_FP8) return encoder_forward_fp8(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
     if (use_small(cfg)) {
         if (cfg->dtype == CP_BF16) return encoder_forward_small_t<bf16_t>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
@@ -965,7 +981,7 @@ static int head_impl(const cp_config* cfg, const cp_params* p, const float* z, c
     a.gneg = gneg;
     const int blocks = grid_rows(n_groups, HEAD_WAVES * (n_groups >= 2048 ? 2 : 1), kHeadBlocksMax);   // (>= 2048 groups: two per wave, half the prologues)
     // CP_FP8 (BASELINE config 4): the logits on the block-scaled 8-bit MFMA; "fp8_head_f32" keeps the f32 products (tests)
-    const bool f8l = cfg->dtype == CP_FP8 && !g_opt.fp8_head_f32;
+    const bool f8l = cfg->dtype == CP_FP8 && !opt(cfg, CP_OPT_FP8_HEAD_F32);
     if (cfg->dtype != CP_F32) {
         if (f8l) {
             if (gneg) hipLaunchKernelGGL((head_kernel<bf16_t, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
@@ -1079,20 +1095,14 @@ extern "C" int cp_emg_normalize(float* seg, int64_t n_rows, const float* mean_st
 // ---------------------------------------------------------------------------------------
 // encoder backward
 // ---------------------------------------------------------------------------------------
-// test aid (cp_debug_set_grad_tap): device buffer of 9 slots x n_windows x 768 elements of the compute dtype that receives a
+// test aid (cp_config.grad_tap): device buffer of 9 slots x n_windows x 768 elements of the compute dtype that receives a
 // copy of every intermediate gradient of the backward pass, so that each backward kernel can be checked on its own
 // inputs at full batch size (tests/test_gpu_fullsize.py).  nullptr (the default) = no copies.
-static size_t g_grad_tap_bytes = 0;
-extern "C" int cp_debug_set_grad_tap(void* tap, size_t bytes) {
-    g_grad_tap = (unsigned char*)tap;
-    g_grad_tap_bytes = tap ? bytes : 0;
-    return 0;
-}
-static int tap_gradient(int slot, const void* src, int64_t n_windows, int width, size_t es, hipStream_t st) {
-    if (!g_grad_tap) return 0;
+static int tap_gradient(const cp_config* c, int slot, const void* src, int64_t n_windows, int width, size_t es, hipStream_t st) {
+    if (!c->grad_tap) return 0;
     const size_t slot_bytes = (size_t)n_windows * 768 * es, bytes = (size_t)n_windows * width * es;
-    if ((size_t)(slot + 1) * slot_bytes > g_grad_tap_bytes) return fail(CP_ERR_ARG, "gradient tap buffer too small");
-    CK(hipMemcpyAsync(g_grad_tap + slot * slot_bytes, src, bytes, hipMemcpyDeviceToDevice, st));
+    if ((size_t)(slot + 1) * slot_bytes > c->grad_tap_bytes) return fail(CP_ERR_ARG, "gradient tap buffer too small");
+    CK(hipMemcpyAsync((unsigned char*)c->grad_tap + slot * slot_bytes, src, bytes, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -1106,8 +1116,10 @@ struct GWS {
 };
 static const int kGlovePartialRows = 2048, kGloveSlabs = 128;
 
+// (CP_FP8 configurations run the glove-angle class encoder -- 0.3 % of the step's FLOPs, K = 20 -- on the bf16 kernels: 8-bit storage
+//  is for the sEMG encoder's activations)
 static GWS carve_glove(int64_t rows, int dtype) {
-    const size_t es = dtype == CP_BF16 ? 2 : 4;
+    const size_t es = dtype == CP_F32 ? 4 : 2;
     GWS g{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
@@ -1131,14 +1143,14 @@ static GWS carve_glove(int64_t rows, int dtype) {
 }
 
 extern "C" size_t cp_glove_workspace_bytes(int64_t max_rows, int32_t dtype) {
-    if (max_rows <= 0 || (dtype != CP_F32 && dtype != CP_BF16)) return 0;
+    if (max_rows <= 0 || (dtype != CP_F32 && dtype != CP_BF16 && dtype != CP_FP8)) return 0;
     return carve_glove(max_rows, dtype).total;
 }
 
 static int check_glove(const cp_config* c, int64_t rows, void* gws, size_t gws_bytes, GWS* out) {
     if (!c || !gws) return fail(CP_ERR_ARG, "null config/glove workspace");
     if (rows <= 0 || rows % CP_TASKS != 0) return fail(CP_ERR_ARG, "glove rows must be a positive multiple of 41");
-    if (c->dtype != CP_F32 && c->dtype != CP_BF16) return fail(CP_ERR_ARG, "dtype");
+    if (c->dtype != CP_F32 && c->dtype != CP_BF16 && c->dtype != CP_FP8) return fail(CP_ERR_ARG, "dtype");
     *out = carve_glove(rows, c->dtype);
     if (out->total > gws_bytes) return fail(CP_ERR_WORKSPACE, "glove workspace too small");
     if (((uintptr_t)gws & 255) != 0) return fail(CP_ERR_ARG, "glove workspace must be 256-byte aligned");
@@ -1193,7 +1205,7 @@ extern "C" int cp_glove_forward(const cp_config* cfg, const cp_glove_params* gp,
     GWS w;
     if (int e = check_glove(cfg, rows, gws, gws_bytes, &w)) return e;
     if (!gp || !gp->w1 || !gp->bn_g || !gp->bn_b || !gp->last_w || !glove || !zg) return fail(CP_ERR_ARG, "cp_glove_forward args");
-    if (cfg->dtype == CP_BF16) return glove_forward_t<bf16_t>(cfg, gp, glove, rows, (unsigned char*)gws, w, zg, (hipStream_t)stream);
+    if (cfg->dtype != CP_F32) return glove_forward_t<bf16_t>(cfg, gp, glove, rows, (unsigned char*)gws, w, zg, (hipStream_t)stream);
     return glove_forward_t<float>(cfg, gp, glove, rows, (unsigned char*)gws, w, zg, (hipStream_t)stream);
 }
 
@@ -1211,7 +1223,6 @@ extern "C" int cp_head_glove(const cp_config* cfg, const float* z, const float* 
     hipStream_t st = (hipStream_t)stream;
     unsigned char* base = (unsigned char*)ws;
     unsigned char* gbase = (unsigned char*)gws;
-    const size_t es = cfg->dtype == CP_BF16 ? 2 : 4;
     ProfScope ps(CP_K_HEAD, st);
     // (no memsets of dz / dzg: head_kernel writes whole 64-element rows)
     HeadArgs a{};
@@ -1219,7 +1230,7 @@ extern "C" int cp_head_glove(const cp_config* cfg, const float* z, const float* 
     a.G = n_groups; a.V = V; a.want_grad = want_grad; a.dz_ld = 64; a.dz = base + w.dz;
     a.logits = logits; a.pred = pred; a.partials = (float*)(base + w.head_part);
     const int blocks = grid_rows(n_groups, HEAD_WAVES * (n_groups >= 2048 ? 2 : 1), kHeadBlocksMax);   // (>= 2048 groups: two per wave, half the prologues)
-    if (cfg->dtype == CP_BF16)
+    if (cfg->dtype != CP_F32)
         hipLaunchKernelGGL((head_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((head_kernel<float, true>), dim3(blocks), dim3(256), 0, st, a);
@@ -1264,7 +1275,7 @@ static int glove_backward_t(const cp_config* c, const cp_glove_params* gp, int64
         GemmNTArgs a{};
         a.A = dzg; a.lda = 64; a.M = R; a.K = 64; a.W = base + w.w2t; a.F = GL_H;
         a.C = gbuf; a.ldc = GL_H; a.R = nullptr; a.ldr = GL_H; a.partials = partials;
-        CK((launch_fc_gemm<T, EPI_DGRAD>(a, st)));
+        CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, nullptr, dyn_tiles(c))));
     }
     // ReLU backward + the BN-backward sums, the coefficients, BN backward
     {
@@ -1298,7 +1309,7 @@ extern "C" int cp_glove_backward(const cp_config* cfg, const cp_glove_params* gp
     if (int e = check_glove(cfg, rows, gws, gws_bytes, &w)) return e;
     if (!gp || !gp->last_w || !grads || !grads->w1 || !grads->bn_g || !grads->bn_b || !grads->last_w)
         return fail(CP_ERR_ARG, "cp_glove_backward args");
-    if (cfg->dtype == CP_BF16) return glove_backward_t<bf16_t>(cfg, gp, rows, (unsigned char*)gws, w, grads, (hipStream_t)stream);
+    if (cfg->dtype != CP_F32) return glove_backward_t<bf16_t>(cfg, gp, rows, (unsigned char*)gws, w, grads, (hipStream_t)stream);
     return glove_backward_t<float>(cfg, gp, rows, (unsigned char*)gws, w, grads, (hipStream_t)stream);
 }
 
@@ -1326,10 +1337,10 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
     const PreReduce pre{partials, (float*)(base + w.partials2), st};
     auto bwd_finalize = [&](const float* pp, int nr, double count, int l, int C, int nfold, const char* what) -> int {
         const float* local = nullptr;
-        if (g_sync_fn) {
-            if (int e = sync_row(pp, nr, 2 * C * nfold, base, w, st, &pp, &local)) return e;
+        if (c->stats_allreduce) {
+            if (int e = sync_row(c, pp, nr, 2 * C * nfold, base, w, st, &pp, &local)) return e;
             nr = 1;
-            count *= g_sync_world;
+            count *= c->stats_world;
         }
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nr, count, stats(l), coef, g->bn_g[l],
                            g->bn_b[l], C, nfold, local);
@@ -1353,7 +1364,7 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
             CKL("bn_relu_bwd_kernel(conv2)");
         }
-        if (int e = tap_gradient(1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
+        if (int e = tap_gradient(c, 1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
         ConvArgs ca{};
         ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0); ca.gin = cur; ca.n_windows = N;
         {
@@ -1385,7 +1396,7 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
             CKL("conv2_strip_kernel<dgrad>");
         }
     }
-    if (int e = tap_gradient(0, nxt, N, 768, sizeof(T), st)) return e;             // dL/d(BN1 output), [w][c]
+    if (int e = tap_gradient(c, 0, nxt, N, 768, sizeof(T), st)) return e;             // dL/d(BN1 output), [w][c]
     // ---- conv1 -----------------------------------------------------------------------------
     {
         ProfScope ps(CP_K_CONV1_BWD, st);
@@ -1424,10 +1435,10 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     // dgamma / dbeta this rank's own sums (the gradient all-reduce adds the ranks' parts).
     auto bwd_finalize = [&](const float* pp, int nr, double count, int l, int C, int nfold, const char* what) -> int {
         const float* local = nullptr;
-        if (g_sync_fn) {
-            if (int e = sync_row(pp, nr, 2 * C * nfold, base, w, st, &pp, &local)) return e;
+        if (c->stats_allreduce) {
+            if (int e = sync_row(c, pp, nr, 2 * C * nfold, base, w, st, &pp, &local)) return e;
             nr = 1;
-            count *= g_sync_world;
+            count *= c->stats_world;
         }
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nr, count, stats(l), coef, g->bn_g[l],
                            g->bn_b[l], C, nfold, local);
@@ -1448,7 +1459,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     T* cur = (T*)(base + w.gbuf[0]);
     T* nxt = (T*)(base + w.gbuf[1]);
     bool bn_done = false;           // (see the comment above the fc loop)
-    const bool fuse_ok = sizeof(T) == 2 && !g_opt.unfused_bn_bwd;
+    const bool fuse_ok = sizeof(T) == 2 && !opt(c, CP_OPT_UNFUSED_BN_BWD);
     // ---- projection ------------------------------------------------------------------
     {
         ProfScope ps(CP_K_PROJ_BWD, st);
@@ -1467,7 +1478,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         int S;
         split_rows(N, 128, &S, &ta.rows_per_split);
 #ifdef CP_VARIANTS
-        const bool fused_u8 = drop && !g_opt.materialize_u8;
+        const bool fused_u8 = drop && !g_var.materialize_u8;
 #else
         const bool fused_u8 = drop;
 #endif
@@ -1502,14 +1513,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             int nr = stat_rows;
             if (int e = bwd_finalize(partials, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, fused)")) return e;
             a.R = act(8); a.coef = coef; a.coef_mod = 512;
-            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
+            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows, dyn_tiles(c))));
             nr = drows;
             const float* pp = pre(nr, 512);
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[6]);
             CKL("colsum_finalize_kernel(fc7, fused)");
             bn_done = true;
 #ifdef CP_VARIANTS
-        } else if (fuse_ok && drop && sizeof(T) == 2 && !g_opt.no_proj_fused) {
+        } else if (fuse_ok && drop && sizeof(T) == 2 && !g_var.no_proj_fused) {
 #else
         } else if (fuse_ok && drop && sizeof(T) == 2) {
 #endif
@@ -1528,7 +1539,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             CKL("colsum_finalize_kernel(fc7, projection)");
             bn_done = true;
         } else {
-            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
+            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows, dyn_tiles(c))));
             if (drop) stat_rows = drows;             // partial rows of BN-backward sums written by this launch
         }
     }
@@ -1556,7 +1567,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(512)), dim3(FIN_THREADS), 0, st, pp, nr, 512, g->fc_b[i]);
             CKL("bn_relu_bwd_kernel");
         }
-        if (int e = tap_gradient(L, cur, N, 512, sizeof(T), st)) return e;        // dL/d(pre-activation of layer L)
+        if (int e = tap_gradient(c, L, cur, N, 512, sizeof(T), st)) return e;        // dL/d(pre-activation of layer L)
         const bool in_drop = drop && Lp >= 5;
         const T* Y = in_drop ? (const T*)(base + w.u[Lp - 5]) : act(Lp);
         const float* s = in_drop ? nullptr : stats(Lp) + 2 * kLayerC[Lp];
@@ -1567,7 +1578,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         // next layer's (the gradient buffer they read is the ping-pong partner, untouched until that layer's data
         // gradient): two problems x 4 tiles x 32 splits fill the GPU with half the f32 slabs per layer (134 -> 67 MB
         // written and re-read).
-        const bool defer_wgrad = sizeof(T) == 2 && in_drop && (i == 6 || i == 4) && fcK(i - 1) == 512 && !g_opt.unpaired_wgrad;
+        const bool defer_wgrad = sizeof(T) == 2 && in_drop && (i == 6 || i == 4) && fcK(i - 1) == 512 && !opt(c, CP_OPT_UNPAIRED_WGRAD);
         if (defer_wgrad) {
             pend.X = cur; pend.Y = Y; pend.i = i;
             pending = true;
@@ -1633,7 +1644,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             int drows = 0;
             {
                 ProfScope ps(CP_K_FC_DGRAD_BN, st);                        // data gradient + BN/ReLU backward of the layer below
-                CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
+                CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows, dyn_tiles(c))));
             }
             {
                 ProfScope ps(CP_K_BN_BWD, st);
@@ -1649,7 +1660,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // the saved activation (one-tile-per-block kernel), otherwise it is the persistent kernel
             ProfScope ps(in_drop ? CP_K_FC_DGRAD_STATS : CP_K_FC_DGRAD, st);
             int drows = 0;
-            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows)));
+            CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows, dyn_tiles(c))));
             if (in_drop) stat_rows = drows;
         }
         T* tmp = cur; cur = nxt; nxt = tmp;
@@ -1680,7 +1691,6 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
     using T = bf16_t;
     const int64_t N = c->n_windows;
     const bool drop = c->training && c->dp_emg > 0.f;
-    if (g_sync_fn) return fail(CP_ERR_ARG, "CP_FP8: synchronised BatchNorm is not wired into the 8-bit path");
     float* partials = (float*)(base + w.partials);
     float* slabs = (float*)(base + w.slabs);
     float* coef = (float*)(base + w.coef);
@@ -1689,16 +1699,22 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     const PreReduce pre{partials, (float*)(base + w.partials2), st};
     auto bwd_finalize = [&](const float* pp, int nr, double count, int l, int C, int nfold, const char* what) -> int {
+        const float* local = nullptr;
+        if (c->stats_allreduce) {          // synchronised BatchNorm (these sums are in true units on this path)
+            if (int e = sync_row(c, pp, nr, 2 * C * nfold, base, w, st, &pp, &local)) return e;
+            nr = 1;
+            count *= c->stats_world;
+        }
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(C)), dim3(FIN_THREADS), 0, st, pp, nr, count, stats(l), coef, g->bn_g[l],
-                           g->bn_b[l], C, nfold, (const float*)nullptr);
+                           g->bn_b[l], C, nfold, local);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : fail((int)e, what);
     };
     auto tap8 = [&](int slot, const uint8_t* src, int t) -> int {          // test aid: the e5m2 gradient expanded into the bf16 tap
-        if (!g_grad_tap) return 0;
+        if (!c->grad_tap) return 0;
         const size_t slot_bytes = (size_t)N * 768 * 2;
-        if ((size_t)(slot + 1) * slot_bytes > g_grad_tap_bytes) return fail(CP_ERR_ARG, "gradient tap buffer too small");
-        hipLaunchKernelGGL(dequant5_bf16_kernel, dim3(1024), dim3(256), 0, st, src, (bf16_t*)(g_grad_tap + slot * slot_bytes), N * 128, fs, t);
+        if ((size_t)(slot + 1) * slot_bytes > c->grad_tap_bytes) return fail(CP_ERR_ARG, "gradient tap buffer too small");
+        hipLaunchKernelGGL(dequant5_bf16_kernel, dim3(1024), dim3(256), 0, st, src, (bf16_t*)((unsigned char*)c->grad_tap + slot * slot_bytes), N * 128, fs, t);
         CKL("dequant5_bf16_kernel");
         return 0;
     };
@@ -1879,12 +1895,22 @@ extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, 
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !grads) return fail(CP_ERR_ARG, "cp_encoder_backward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
+    // the path is the FORWARD's: use_small() ignores `training`, which a backward call may not carry, only through (training || adabn)
+    const int repeats = note_backward(ws, cfg->n_windows, forward_path(cfg));
+    if (repeats == -1)
+        return fail(CP_ERR_ARG, "cp_encoder_backward: the configuration (n_windows, dtype, options, hooks) differs from the forward pass that filled this workspace");
+    if (repeats == -2) return fail(CP_ERR_ARG, "cp_encoder_backward: no cp_encoder_forward has run on this workspace");
     if (cfg->dtype != CP_FP8 && use_small(cfg)) {
+        if (repeats > 0) {
+            // a second backward over the same forward: the small-batch form's BatchNorm-backward totals (fixed-point atomics, zeroed by the
+            // forward's preparation launch) already hold the first pass's sums
+            CK(hipMemsetAsync((unsigned char*)ws + w.sm_acc + (size_t)9 * 2 * 768 * 8, 0, (size_t)9 * 2 * 768 * 8, (hipStream_t)stream));
+        }
         if (cfg->dtype == CP_BF16)
             return encoder_backward_small_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
         return encoder_backward_small_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
     }
-    if (cfg->dtype == CP_FP8 && !g_opt.fp8_bridge)
+    if (cfg->dtype == CP_FP8 && !opt(cfg, CP_OPT_FP8_BRIDGE))
         return encoder_backward_fp8(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
     if (cfg->dtype == CP_FP8) {
         // (bridge = the first build's route, kept for A/B runs and as the test's comparison: the e4m3 tensors of the forward pass are
@@ -2050,14 +2076,16 @@ extern "C" int cp_debug_activation(const cp_config* cfg, const cp_params* p, con
     }
     const size_t off = layer < CP_N_BN ? w.act[layer] : w.u[layer - CP_N_BN];
 #ifdef CP_VARIANTS
-    const bool u8_stored = g_opt.materialize_u8 != 0;
+    const bool u8_stored = g_var.materialize_u8 != 0;
 #else
     const bool u8_stored = false;
 #endif
     (void)u8_stored;
-    if (layer >= CP_N_BN) {
-        // dropout(BN(.)) is recomputed from the stored activation with the forward pass's key -- bit for bit what the large-batch
-        // forward stores for fc4..fc6, and the only way to see it for fc7 and after a small-batch forward (csrc/small.cuh)
+    // dropout(BN(.)) of fc4..fc6 is STORED by the large-batch forward: read what it stored.  fc7's (formed while staging, never
+    // written) and all four after a small-batch forward (csrc/small.cuh applies BatchNorm + dropout while staging) are recomputed from
+    // the stored activation with the forward pass's key, into the otherwise unused buffer.
+    const bool stored_u = layer >= CP_N_BN && layer < CP_N_BN + 3 && last_forward_path(ws) == PATH_LARGE && !u8_stored;
+    if (layer >= CP_N_BN && !stored_u && !(u8_stored && layer == CP_N_BN + 3)) {
         const int Lp = 5 + (layer - CP_N_BN);
         const int64_t N = cfg->n_windows;
         const float* stp = (const float*)(base + w.stats[Lp]);

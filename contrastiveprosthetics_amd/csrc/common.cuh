@@ -13,22 +13,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CP_WAVE 64
 
-// Process-wide switches of the library, set through cp_debug_set_option (include/cpnative.h) -- never read from the environment on
-// a launch path.  The product library knows five: orders / forms of the SAME computation that tests compare.  A tools-only build with
-// -DCP_VARIANTS (make -C csrc variants -> build/libcpnative_variants.so) also carries the kernels that were measured and
-// superseded, with one switch each; there $CPNATIVE_<NAME> seeds the switch once when the library is loaded (tools/ab_env.sh).
-struct CpOptions {
-    int unfused_bn_bwd = 0;      // BatchNorm + ReLU backward as its own pass behind every data gradient (the f32 path's order)
-    int unpaired_wgrad = 0;      // one weight-gradient launch per layer behind a dropout instead of paired launches
-    int fp8_bridge = 0;          // CP_FP8: expand the saved 8-bit tensors to bf16 and run the bf16 backward kernels
-    int no_small = 0;            // batches of <= 64 groups on the large-batch kernels instead of the small-batch form (csrc/small.cuh)
-    int fp8_head_f32 = 0;        // CP_FP8: the head's logits from the f32 MFMAs instead of the block-scaled 8-bit one (head.cuh, F8L)
+// The product library has NO process-wide switches: everything a call depends on travels in its cp_config (include/cpnative.h:
+// options, tile_schedule, the synchronised-BatchNorm hook, the gradient tap), so two engines in one process cannot see each other's
+// settings.  Only the tools-only build (-DCP_VARIANTS: make -C csrc variants -> build/libcpnative_variants.so), which also carries
+// the kernels that were measured and superseded (tools/variants/*.cuh), keeps a global: one switch per superseded kernel, seeded
+// ONCE from $CPNATIVE_<NAME> when that library is loaded (tools/ab_env.sh).
 #ifdef CP_VARIANTS
+struct CpVariantOptions {
     int no_ws = 0, no_wsk = 0, no_wsd = 0, no_wsd_st = 0, staged_r_epilogue = 0, ws32 = 0, wsd32 = 0, tn_w4 = 0, tn16 = 0,
         materialize_u8 = 0, no_proj_fused = 0;
-#endif
 };
-static CpOptions g_opt;
+static CpVariantOptions g_var;
+#endif
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {                   // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
@@ -133,16 +129,21 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 // full-rate 24-bit multiply (v_mul_u32_u24): fold, multiply, key, fold, then two multiplies of the same word by different
 // constants give 2 x 32 bits.  Round 3: the first form (two 32-bit multiplies per PAIR -- v_mul_lo_u32 issues at quarter rate)
 // made the 8-bit dropout pass and the data-gradient epilogue behind a dropout VALU-bound (SQ_ACTIVE_INST_VALU 2.4x the matrix
-// pipe's busy cycles); this one is 13 full-rate instructions per four elements.  Checked in numpy on 4M consecutive indices
-// (tools/dropout_hash_check.py): drop rates 0.0633-0.0635 for p = 0.0635 in all four draws (and 0.00988..0.50013 for p = 0.01..0.5),
-// cross-draw, lag-1, lag-128 (next row) and key-bit-flip mask correlations all below 0.0025.
+// pipe's busy cycles); this one is 18 full-rate instructions per four elements.
+// Round 4: ALL 32 bits of the quad index stay live.  A 24-bit multiply reads the low 24 bits of its operand, so round 3's chain kept
+// 24 bits of state and tensors of more than 2^24 quads (131,072 rows x 512: the bench's 167,936) re-used whole rows of masks.  Now the
+// index's top byte enters through its own multiply, and the second output word is drawn from another 24-bit window of the state.
+// tools/dropout_hash_check.py (numpy, bit for bit; a CPU test runs it): no two rows of a 167,936 x 512 or a 335,872 x 512 tensor share a
+// mask (round 3's form: 36,864 / 204,800 rows), drop rates 0.0634-0.0636 for p = 0.0635 in all four draws, cross-draw, lag-1, next-row,
+// 2^22 / 2^24 / 2^25-quad-lag and key-bit-flip mask correlations all below 0.004.  Limit: row * ld < 2^32 (api.hip checks n_windows).
 __device__ __forceinline__ uint2 dropout_quad(uint32_t key, uint32_t row, uint32_t ld, uint32_t col) {
-    uint32_t x = ((__umul24(row, ld) + col) >> 2) ^ key;        // (rows and ld below 2^24)
+    uint32_t x = ((__umul24(row, ld) + col) >> 2) ^ key;        // (rows and ld below 2^24, rows * ld below 2^32)
+    const uint32_t hi = x >> 24;
     x ^= x >> 15;
-    x = __umul24(x, 0xB5297Bu);
+    x = __umul24(x, 0xB5297Bu) ^ __umul24(hi, 0x9E3779u);
     x ^= (key >> 16) | (key << 16);
     x ^= x >> 13;
-    uint32_t a = __umul24(x, 0x8DA6B5u), b = __umul24(x, 0x3C6EF3u);
+    uint32_t a = __umul24(x, 0x8DA6B5u), b = __umul24(x ^ (x >> 11), 0x3C6EF3u);
     a ^= a >> 16;
     b ^= b >> 16;
     return make_uint2(a, b);

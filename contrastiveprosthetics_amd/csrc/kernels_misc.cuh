@@ -444,14 +444,21 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 
 // out[c] = sum_rows partials[row][c]  (f64 accumulation; one thread per column)
 // grid FIN_GRID(C) blocks of FIN_THREADS
+// unscale_exp (CP_FP8 statistics rows [sum | sum of squares] of values stored with the scale 2^e, else nullptr): columns below
+// `half` are multiplied by 2^-e, the others by 2^-2e -- the row in true units (synchronised BatchNorm: every rank has its own e)
 __global__ __launch_bounds__(FIN_THREADS) void colsum_finalize_kernel(const float* __restrict__ partials, int nrows, int C,
-                                                                      float* __restrict__ out) {
+                                                                      float* __restrict__ out, const int* __restrict__ unscale_exp = nullptr,
+                                                                      int half = 0) {
     __shared__ double red[FIN_THREADS / 64][FIN_COLS];
     const int tid = threadIdx.x, cl = tid % FIN_COLS, g = tid / FIN_COLS;
     const int c = blockIdx.x * FIN_COLS + cl;
     double s = 0;
     if (c < C) fin_fold_rows(partials + c, nrows, g, FIN_LANES, C, s);
     s = fin_block_sum(s, red, tid);
+    if (unscale_exp != nullptr) {
+        const double d = (double)f8_exp2i(-*unscale_exp);
+        s *= c < half ? d : d * d;
+    }
     if (g == 0 && c < C) out[c] = (float)s;
 }
 

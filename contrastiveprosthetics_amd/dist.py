@@ -26,17 +26,29 @@ def rank() -> int:
     return td.get_rank() if td.is_available() and td.is_initialized() else 0
 
 
+_default_tiles = None        # None: $CPNATIVE_TILE_SCHEDULE or static
+
+
+def default_tile_schedule() -> str:
+    """The tile schedule an Engine built from now on starts with ("static" | "dynamic"; cp_config.tile_schedule,
+    include/cpnative.h): what share_gpu_with_other_kernels() chose, else $CPNATIVE_TILE_SCHEDULE, else static.  Read by
+    Engine.__init__ -- the library itself reads no environment variable."""
+    if _default_tiles is not None:
+        return _default_tiles
+    return "dynamic" if os.environ.get("CPNATIVE_TILE_SCHEDULE") == "dynamic" else "static"
+
+
 def share_gpu_with_other_kernels():
-    """Tell the library that its GEMM launches will run beside other processes' kernels on the same GPU (a packed
-    sweep): tiles are then drawn dynamically (cp_set_tile_schedule, include/cpnative.h) unless $CPNATIVE_TILE_SCHEDULE
-    says otherwise.  Data-parallel runs keep the static schedule: the collectives are placed so that at most one
-    persistent GEMM launch per step (the projection's data gradient) can meet RCCL's kernels -- the z all-gather runs
-    beside the head and the projection's backward, the large gradient bucket beside the conv backward -- and a
-    late-starting launch costs less there than the dynamic schedule's 2 % on all fifteen."""
-    if os.environ.get("CPNATIVE_TILE_SCHEDULE") or not torch.cuda.is_available():
+    """The engines this process builds will run their GEMM launches beside other processes' kernels on the same GPU (a
+    packed sweep): they draw their tiles dynamically (Engine.tile_schedule -> cp_config.tile_schedule) unless
+    $CPNATIVE_TILE_SCHEDULE says otherwise.  Data-parallel runs keep the static schedule: the collectives are placed so
+    that at most one persistent GEMM launch per step (the projection's data gradient) can meet RCCL's kernels -- the z
+    all-gather runs beside the head and the projection's backward, the large gradient bucket beside the conv backward --
+    and a late-starting launch costs less there than the dynamic schedule's 2 % on all fifteen."""
+    global _default_tiles
+    if os.environ.get("CPNATIVE_TILE_SCHEDULE"):
         return
-    from . import _lib
-    _lib.check(_lib.load().cp_set_tile_schedule(1), "cp_set_tile_schedule")
+    _default_tiles = "dynamic"
 
 
 def init_from_env(backend: str = None) -> Tuple[int, int]:

@@ -178,8 +178,6 @@ class Engine:
             raise ValueError(f"the HIP head kernel is built for d_e={CP_D_E} (code/train.py:183), got {d_e}")
         if dtype not in ("f32", "bf16", "fp8"):
             raise ValueError("dtype must be 'f32', 'bf16' or 'fp8'")
-        if dtype == "fp8" and class_encoder != "onehot":
-            raise ValueError("dtype 'fp8' (BASELINE config 4) covers the one-hot class encoder")
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -225,6 +223,16 @@ class Engine:
         self._gws: Optional[torch.Tensor] = None
         self._gws_rows = 0
         self._graph_state: Optional[torch.Tensor] = None      # device cp_step_state while a GraphStep owns the engine
+        # per-engine call state, carried in every cp_config (the library has no process-wide switches)
+        self.options: Dict[str, int] = {}                     # _lib.OPTIONS names -> 0/1 (tests, measurements)
+        self.tile_schedule = _lib.CP_TILES_STATIC             # dist.use_dynamic_tiles() flips the default for packed sweeps
+        from . import dist as _cpdist
+        if _cpdist.default_tile_schedule() == "dynamic":
+            self.tile_schedule = _lib.CP_TILES_DYNAMIC
+        self._sync_cb = None
+        self._sync_world = 1
+        self._fp8_seen_forward = False
+        self.grad_tap: Optional[torch.Tensor] = None          # test aid (cp_config.grad_tap)
         self._ws: Optional[torch.Tensor] = None
         self._ws_windows = 0
         names = list(self.specs)
@@ -255,6 +263,18 @@ class Engine:
         c.bn_eps = 1e-5
         c.seed = self.seed
         c.step = self.step_count
+        bits = 0
+        for k, v in self.options.items():
+            if v:
+                bits |= _lib.OPTIONS[k]                      # KeyError = unknown option
+        c.options = bits
+        c.tile_schedule = self.tile_schedule
+        if self._sync_cb is not None:
+            c.stats_allreduce = C.cast(self._sync_cb, C.c_void_p)
+            c.stats_world = self._sync_world
+        if self.grad_tap is not None:
+            c.grad_tap = self.grad_tap.data_ptr()
+            c.grad_tap_bytes = self.grad_tap.numel() * self.grad_tap.element_size()
         return c
 
     def workspace(self, n_windows: int) -> torch.Tensor:
@@ -264,11 +284,18 @@ class Engine:
         graph's alone instead of handing it back to the caching allocator."""
         if self._ws is None or n_windows > self._ws_windows:
             nbytes = self.lib.cp_workspace_bytes(n_windows, self.dtype, self.dp_emg)
+            # CP_FP8: the tensors' scales live in the first KiB of the workspace across steps (csrc/fp8.cuh, Fp8State).  RULE: the
+            # table belongs to the engine, not to a buffer -- a grown workspace (the first validate() after training: 25x the
+            # rows) inherits it, so evaluation starts from the scales training arrived at; only the engine's first workspace
+            # starts from the defaults (zero-filled).  tests/test_gpu_fp8_product.py::test_scale_table_survives_reallocation.
+            keep = self._ws[:_lib.FP8_STATE_BYTES].clone() if (self.dtype == CP_FP8 and self._ws is not None) else None
             self._ws = None                                   # (frees the old block first unless a GraphStep holds it)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             if self.dtype == CP_FP8:
-                # the tensors' scales live here across steps (csrc/fp8.cuh, Fp8State): a fresh workspace starts from the defaults
-                self._ws[:_lib.FP8_STATE_BYTES].zero_()
+                if keep is not None:
+                    self._ws[:_lib.FP8_STATE_BYTES].copy_(keep)
+                else:
+                    self._ws[:_lib.FP8_STATE_BYTES].zero_()
             self._ws_windows = n_windows
         return self._ws
 
@@ -295,6 +322,13 @@ class Engine:
         z = torch.empty(n, CP_D_E, dtype=torch.float32, device=self.device)
         ws, nb = self._ws_args(n)
         bn = C.byref(self._bn) if not self.adabn else None
+        if self.dtype == CP_FP8 and not training and not self._fp8_seen_forward:
+            # CP_FP8 scales are "delayed": a forward pass stores with the scales the PREVIOUS pass measured.  An engine whose first
+            # pass ever is an evaluation (results.py on a loaded checkpoint) has only the defaults (2^4: clips at 28), so that
+            # batch runs twice -- the first time to measure.  (Training needs no such pass: one clipped step among thousands.)
+            _lib.check(self.lib.cp_encoder_forward(C.byref(cfg), C.byref(self._p), bn, x.data_ptr(), ws, nb, z.data_ptr(),
+                                                   self._stream()), "cp_encoder_forward")
+        self._fp8_seen_forward = True
         _lib.check(self.lib.cp_encoder_forward(C.byref(cfg), C.byref(self._p), bn, x.data_ptr(), ws, nb, z.data_ptr(),
                                                self._stream()), "cp_encoder_forward")
         if training and not self.adabn:
@@ -365,14 +399,16 @@ class Engine:
     def set_sync_bn(self, allreduce=None, world: int = 1):
         """allreduce(tensor): sums a 1-D f32 device tensor over the ranks in place (e.g. torch.distributed.all_reduce),
         ordered on the current stream; None switches synchronised BatchNorm off.  While set, every BatchNorm of the sEMG
-        encoder normalises with the statistics of the global batch (cp_set_stats_allreduce, 18 small collectives per
-        training step).  Process-wide: one engine at a time."""
+        encoder normalises with the statistics of the global batch (cp_config.stats_allreduce, 18 small collectives per
+        training step).  Per engine: the hook travels in this engine's cp_config."""
         if allreduce is None:
-            _lib.check(self.lib.cp_set_stats_allreduce(None, None, 1), "cp_set_stats_allreduce")
             self._sync_cb = None
+            self._sync_world = 1
             return
         if self.class_encoder == "glove":
             raise _lib.CpNativeError("synchronised BatchNorm covers the sEMG encoder; the glove-angle class encoder's BatchNorm stays local")
+        if int(world) < 1:
+            raise ValueError("world")
         eng = self
 
         def cb(user, row_ptr, count, stream):
@@ -389,7 +425,7 @@ class Engine:
                 return 10004
 
         self._sync_cb = _lib.ALLREDUCE_FN(cb)                # keep the trampoline alive
-        _lib.check(self.lib.cp_set_stats_allreduce(C.cast(self._sync_cb, C.c_void_p), None, int(world)), "cp_set_stats_allreduce")
+        self._sync_world = int(world)
 
     # ------------------------------------------------------------------ glove-angle class encoder (row f2)
     def _gws_args(self, rows: int):

@@ -116,7 +116,7 @@ class Model(nn.Module):
         batch): training batches take the class->EMG direction of the loss over the z embeddings of the GLOBAL batch
         (global_negatives=True or "gather": one RCCL all-gather of z per step, cp_global_negatives / cp_head_gneg;
         "reduce": the same table from per-rank partial sums and two 64-float all-reduces, cp_global_negatives_g / _h, no z
-        moves) / every BatchNorm of the sEMG encoder uses the statistics of the global batch (cp_set_stats_allreduce)."""
+        moves) / every BatchNorm of the sEMG encoder uses the statistics of the global batch (cp_config.stats_allreduce)."""
         super().__init__()
         if prediction or glove:
             raise NotImplementedError("only the contrastive mode (prediction=False, glove=False) is accelerated; "
@@ -141,9 +141,7 @@ class Model(nn.Module):
             raise NotImplementedError("global negatives need the shared one-hot class table")
         from . import dist as cpdist
         if self.sync_bn and cpdist.world_size() > 1:
-            self.engine.set_sync_bn(cpdist.all_reduce_sum_, cpdist.world_size())
-        else:
-            self.engine.set_sync_bn(None)                  # the hook is process-wide: the newest Model decides
+            self.engine.set_sync_bn(cpdist.all_reduce_sum_, cpdist.world_size())      # (per engine: carried in its cp_config)
         self.emg_net = EMGNet()
         self.glove_net = GLOVENet()
         for k in self.engine.specs:

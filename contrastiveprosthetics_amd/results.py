@@ -162,7 +162,7 @@ def build_parser():
     parser.add_argument("--test", action="store_true")
     # additive
     parser.add_argument("--synthetic", action="store_true", help="seeded Ninapro-shaped tensors instead of emg.pt/glove.pt")
-    parser.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    parser.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp8"])
     parser.add_argument("--data_dir", default="../data")
     parser.add_argument("--checkpoint_dir", default="../checkpoints")
     parser.add_argument("--save", default="../data/")

@@ -273,7 +273,10 @@ def build_parser():
     parser.add_argument("--test", action="store_true")
     # additive
     parser.add_argument("--synthetic", action="store_true", help="seeded Ninapro-shaped tensors instead of emg.pt/glove.pt")
-    parser.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="activation storage / MFMA input type")
+    parser.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp8"],
+                        help="activation storage / matrix-instruction input type: f32 = the reference's precision (parity path), bf16, "
+                             "fp8 = e4m3 activations + fc weights and e5m2 gradients on the block-scaled MFMA (BASELINE config 4; parity "
+                             "unpinned by construction, tests/test_gpu_fp8_product.py holds its accuracy to the f32 path's)")
     parser.add_argument("--data_dir", default="../data")
     parser.add_argument("--checkpoint_dir", default="../checkpoints")
     parser.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],

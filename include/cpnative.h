@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CP_VERSION 100            /* 0.1.0 */
+#define CP_VERSION 110            /* 0.1.1: per-call state (cp_config carries options, tile schedule, sync-BN hook, gradient tap) */
 #define CP_F32 0
 #define CP_BF16 1
 #define CP_FP8 2                  /* e4m3 activations and fc weights on the block-scaled MFMA (BASELINE config 4); see cp_config.dtype */
@@ -63,10 +63,37 @@ typedef struct cp_bn_buffers {
     float* running_var[CP_N_BN];
 } cp_bn_buffers;
 
+/* Synchronised-BatchNorm hook (see cp_config.stats_allreduce below): adds one row of `count` floats over all ranks in place. */
+typedef int (*cp_allreduce_fn)(void* user, void* row_dev, int64_t count, void* stream);
+
+/* Test / measurement switches of one call (cp_config.options; all 0 in production).  They select orders or forms of the SAME
+ * computation that tests compare.  The library has no process-wide switch and reads no environment variable. */
+#define CP_OPT_UNFUSED_BN_BWD 1u  /* BatchNorm + ReLU backward as its own pass behind every data gradient (the f32 path's order, on the bf16 kernels) */
+#define CP_OPT_UNPAIRED_WGRAD 2u  /* one weight-gradient launch per layer behind a dropout instead of paired launches */
+#define CP_OPT_FP8_BRIDGE 4u      /* CP_FP8: expand the saved 8-bit tensors to bf16 and run the bf16 backward kernels */
+#define CP_OPT_NO_SMALL 8u        /* batches of <= 64 groups on the large-batch kernels instead of the small-batch form */
+#define CP_OPT_FP8_HEAD_F32 16u   /* CP_FP8: the head's logits from the f32 matrix instruction instead of the block-scaled 8-bit one */
+#define CP_OPT_FINALIZE_LAUNCHES 32u /* large batches: BatchNorm statistics through partial rows + finalize launches (round 3's form) instead of
+                                      * fixed-point atomic totals finalised by the consumer */
+
+/* How the persistent fc GEMM kernels hand their output tiles to the CUs (cp_config.tile_schedule).  CP_TILES_STATIC: each
+ * workgroup owns a fixed list of tiles -- fastest when this process has the GPU to itself (weight-stationary kernels).
+ * CP_TILES_DYNAMIC: workgroups draw tiles from per-XCD counters -- 2-4 % slower alone, but a launch that shares CUs with
+ * another stream's or process's kernels (a packed sweep, collectives that stay resident for long) no longer waits for its
+ * latest-starting workgroup (+35 % with 8-32 CUs held).  BatchNorm partial sums are grouped per sample tile in the dynamic
+ * mode and per workgroup in the static one, so the two differ in the last bits; each is run-to-run reproducible.
+ * (The dynamic schedule's tile counters live in a module-global device table with one slot per stream: the only device-side
+ * state shared between engines, and two streams never share a slot.) */
+enum { CP_TILES_STATIC = 0, CP_TILES_DYNAMIC = 1 };
+
+/* Everything a call depends on besides its tensors.  The library keeps NO per-process state for the training path: two
+ * engines (two cp_config / workspace pairs) in one process, on one or several streams, do not see each other.  The config of
+ * a cp_encoder_backward call must equal that of the cp_encoder_forward call whose workspace it consumes (the library checks
+ * the kernel path and the size and returns CP_ERR_ARG otherwise). */
 typedef struct cp_config {
     int64_t n_windows;   /* rows through the encoder = groups * 41 (train: B*41, eval: B*41*25) */
     int32_t dtype;       /* CP_F32 | CP_BF16 | CP_FP8 (the first F8_STATE_BYTES = 1024 bytes of a CP_FP8 workspace hold the tensors' scales across
-                          * steps: zero them once after allocating it) */
+                          * steps: zero them once after allocating it; see cp_fp8_copy_state) */
     int32_t adabn;       /* 1: batch statistics in train AND eval (AdaBN); 0: stock BN */
     int32_t training;    /* 1: model.train()  (batch stats, dropout, running-stat update) */
     uint32_t step_state_lo; /* low / high half of the DEVICE address of a cp_step_state, or 0/0 (see below) */
@@ -76,6 +103,26 @@ typedef struct cp_config {
     uint32_t step_state_hi;
     uint64_t seed;       /* dropout stream = f(seed, step, layer, element) */
     uint64_t step;
+    uint32_t options;    /* CP_OPT_* bits; 0 in production */
+    int32_t tile_schedule;   /* CP_TILES_STATIC (0, default) | CP_TILES_DYNAMIC */
+    /* ---- synchronised BatchNorm (opt-in: NULL = every rank normalises with its own shard's statistics, which is
+     * the reference at B_local, code/models.py:17-35,238-243).  With a hook, every BatchNorm of the sEMG encoder takes its
+     * batch statistics -- and, in the backward pass, the two sums of BatchNorm's data gradient -- over ALL ranks: the library
+     * folds its partial sums into one row of `count` floats in the workspace and calls stats_allreduce(stats_user, row, count,
+     * stream), which must add the rows of all ranks in place, ordered after the work already on `stream` and before what is
+     * enqueued on it next (torch.distributed.all_reduce on that memory does exactly this).  stats_world = number of ranks (the
+     * element count is scaled by it).  gamma / beta gradients stay this rank's part, as in torch.nn.SyncBatchNorm.  18 calls
+     * per training step. */
+    cp_allreduce_fn stats_allreduce;
+    void* stats_user;
+    int32_t stats_world;
+    int32_t reserved0;
+    /* ---- test aid: while grad_tap is non-NULL, cp_encoder_backward copies every intermediate gradient into it (stream-ordered):
+     * 9 slots of n_windows x 768 elements of the compute dtype; slot L = 2..8: dL/d(pre-activation of fc layer L-1), i.e. after
+     * BatchNorm + ReLU backward, n_windows x 512; slot 1: dL/d(conv2 pre-activation), slot 0: dL/d(BN1 output), both
+     * n_windows x [12 positions][64 channels].  grad_tap_bytes = size of the buffer. */
+    void* grad_tap;
+    size_t grad_tap_bytes;
 } cp_config;
 
 /* Per-step values kept in DEVICE memory so that a whole training step can be captured in a HIP graph and replayed
@@ -93,25 +140,9 @@ typedef struct cp_step_state {
 int cp_version(void);
 const char* cp_last_error(void);
 
-/* Process-wide switches, for tests and measurements (never read from the environment on a launch path).  The product library
- * knows "unfused_bn_bwd" (BatchNorm + ReLU backward as its own pass behind every data gradient: the f32 path's order, on the
- * bf16 kernels), "unpaired_wgrad" (one weight-gradient launch per layer behind a dropout) and "fp8_bridge" (CP_FP8: expand the
- * saved 8-bit tensors to bf16 and run the bf16 backward kernels), "no_small" (batches of <= 64 groups on the large-batch kernels) and
- * "fp8_head_f32" (CP_FP8: the head's logits from the f32 matrix instruction instead of the block-scaled 8-bit one); value 0 / 1.  The tools-only build (make -C csrc variants,
- * cp_has_variants() == 1) also carries the superseded kernels with one switch each.  Unknown name: CP_ERR_ARG. */
-int cp_debug_set_option(const char* name, int32_t value);
+/* 1 in the tools-only build (make -C csrc variants), which also carries the superseded kernels of tools/variants/ with one
+ * $CPNATIVE_<NAME> switch each; 0 in the product library. */
 int cp_has_variants(void);
-
-/* How the persistent fc GEMM kernels (14 launches per step) hand their output tiles to the CUs; process-wide,
- * read at every launch.  CP_TILES_STATIC: each workgroup owns a fixed list of tiles -- fastest when this process
- * has the GPU to itself.  CP_TILES_DYNAMIC: workgroups draw tiles from per-XCD counters -- 2-4 % slower alone, but
- * a launch that shares CUs with another stream's or process's kernels (a packed sweep, collectives that stay
- * resident for long) no longer waits for its latest-starting workgroup (+35 % with 8-32 CUs held).  BatchNorm partial
- * sums are grouped per sample tile in the dynamic mode and per workgroup in the static one, so the two differ in
- * the last bits; each is run-to-run reproducible.  Default: static, or $CPNATIVE_TILE_SCHEDULE (static|dynamic). */
-enum { CP_TILES_STATIC = 0, CP_TILES_DYNAMIC = 1 };
-int cp_set_tile_schedule(int32_t mode);
-int cp_get_tile_schedule(void);
 
 /* bytes of scratch needed by the calls below for up to `max_windows` encoder rows */
 size_t cp_workspace_bytes(int64_t max_windows, int32_t dtype, float dp_emg);
@@ -173,16 +204,6 @@ int cp_global_negatives_g(const cp_params* p, const float* z_local, int64_t n_lo
                           float* scratch, float* gh, void* stream);
 int cp_global_negatives_h(int64_t n_local_windows, const int64_t* labels, float* scratch, float* gh, void* stream);
 
-/* ---- synchronised BatchNorm (opt-in, default off = every rank normalises with its own shard's statistics,
- * which is the reference at B_local, code/models.py:17-35,238-243) ----------------------------------------------------
- * While a hook is set, every BatchNorm of the sEMG encoder takes its batch statistics -- and, in the backward pass, the two
- * sums of BatchNorm's data gradient -- over ALL ranks: the library folds its partial sums into one row of `count` floats
- * in the workspace and calls fn(user, row, count, stream), which must add the rows of all ranks in place, ordered after
- * the work already on `stream` and before what is enqueued on it next (torch.distributed.all_reduce on that memory does
- * exactly this).  world = number of ranks (the element count is scaled by it).  gamma / beta gradients stay this rank's
- * part, as in torch.nn.SyncBatchNorm.  fn == NULL removes the hook.  18 calls per training step. */
-typedef int (*cp_allreduce_fn)(void* user, void* row_dev, int64_t count, void* stream);
-int cp_set_stats_allreduce(cp_allreduce_fn fn, void* user, int32_t world);
 
 /* autograd of EMGNet (what loss.backward() does at code/train.py:105 for emg_net):
  * consumes dL/dz left in ws by cp_head, writes every emg_net gradient into `grads`. */
@@ -338,11 +359,6 @@ int cp_debug_gemm(int32_t dtype, int32_t kind, int64_t M, int32_t K, int32_t F, 
                   const void* W, void* C, const float* bias, const void* R, float* partials,
                   int32_t dbg, void* stream);
 
-/* test aid: while `tap` is non-NULL, cp_encoder_backward copies every intermediate gradient into it (stream-ordered):
- * 9 slots of n_windows x 768 elements of the compute dtype; slot L = 2..8: dL/d(pre-activation of fc layer L-1), i.e. after
- * BatchNorm + ReLU backward, n_windows x 512; slot 1: dL/d(conv2 pre-activation), slot 0: dL/d(BN1 output), both
- * n_windows x [12 positions][64 channels].  bytes = size of the buffer.  NULL switches the copies off (the default). */
-int cp_debug_set_grad_tap(void* tap, size_t bytes);
 
 /* BN statistics of `layer` as computed by the last forward: out[4][C] = mean, invstd, scale, shift */
 int cp_debug_bn_stats(const cp_config* cfg, void* ws, size_t ws_bytes, int32_t layer, float* out,

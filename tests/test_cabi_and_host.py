@@ -41,14 +41,21 @@ def test_header_symbols_exported_and_bound(lib):
         assert hasattr(raw, n), f"{n} declared in cpnative.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes prototype in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.cp_version() == 100
+    assert lib.cp_version() == 110
 
 
 def test_struct_layouts_match_header():
     from contrastiveprosthetics_amd import _lib
     assert ctypes.sizeof(_lib.cp_params) == 8 * (4 + 7 + 7 + 9 + 9 + 3)
     assert ctypes.sizeof(_lib.cp_bn_buffers) == 8 * 18
-    assert ctypes.sizeof(_lib.cp_config) == 8 + 4 * 4 + 4 * 4 + 8 + 8
+    # 56 bytes of round 1-3 fields + options, tile_schedule, the sync-BN hook (fn, user, world, pad) and the gradient tap (ptr, bytes)
+    assert ctypes.sizeof(_lib.cp_config) == (8 + 4 * 4 + 4 * 4 + 8 + 8) + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = hdr[hdr.index("typedef struct cp_config {"):hdr.index("} cp_config;")]
+    fields = re.findall(r"\b(\w+)\s*;", body)
+    assert fields == [f[0] for f in _lib.cp_config._fields_], fields
+    for name, bit in _lib.OPTIONS.items():
+        assert re.search(r"#define CP_OPT_%s %du\b" % (name.upper(), bit), open(HEADER).read()), name
     assert ctypes.sizeof(_lib.cp_adam_hyper) == 32
 
 
@@ -190,13 +197,38 @@ def test_no_buffer_store_is_followed_by_a_write_of_its_data_registers():
 
 
 def test_no_getenv_on_a_launch_path():
-    """the library reads the environment in two places only: the tile schedule's default (cached at first use) and, in the tools-only
-    build, the one-time seeding of the variant switches (csrc/api.hip, seed_options_from_env)"""
+    """the product library never reads the environment (a call's settings travel in its cp_config); the tools-only build reads it
+    once, when it is loaded, to seed the variant switches (csrc/api.hip, seed_variants_from_env, under #ifdef CP_VARIANTS)"""
     import glob
     hits = []
     for f in glob.glob(os.path.join(ROOT, "contrastiveprosthetics_amd", "csrc", "*")):
         for i, line in enumerate(open(f, errors="replace")):
             if "getenv(" in line and not line.lstrip().startswith("//"):
                 hits.append((os.path.basename(f), i + 1, line.strip()))
-    assert len(hits) == 2 and all(h[0] == "api.hip" for h in hits), hits
-    assert any("CPNATIVE_TILE_SCHEDULE" in h[2] for h in hits) and any("getenv(env)" in h[2] for h in hits), hits
+    assert len(hits) == 1 and hits[0][0] == "api.hip" and "getenv(env)" in hits[0][2], hits
+    src = open(os.path.join(ROOT, "contrastiveprosthetics_amd", "csrc", "api.hip")).read()
+    block = src[src.index("static int seed_variants_from_env()"):]
+    assert src[:src.index("static int seed_variants_from_env()")].rstrip().split("#")[-1].startswith("ifdef CP_VARIANTS") or \
+        "#ifdef CP_VARIANTS" in src[src.index("extern \"C\" int cp_has_variants"):src.index("static int seed_variants_from_env()")]
+    # and nothing process-wide is left for the training path to consult
+    assert not re.search(r"^static [^(]*\bg_(opt|sync_fn|sync_user|sync_world|grad_tap|tile_schedule)\b", src, flags=re.M)
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True, check=True).stdout
+
+
+def test_dropout_hash_keeps_every_index_bit_live():
+    """the round-3 hash kept 24 bits of state, so a 167,936 x 512 tensor re-used whole rows of masks.  The numpy emulation
+    of csrc/common.cuh::dropout_quad (tools/dropout_hash_check.py) at the bench's tensor size: no two rows share a mask, the drop
+    rate and the correlations (neighbours, rows, the 2^22 / 2^24-quad lags, key bits) are those of independent draws; the emulation of
+    the superseded form must FAIL the same structural test (so the test is known to see the defect)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dropout_hash_check as dh
+    cu = open(os.path.join(ROOT, "contrastiveprosthetics_amd", "csrc", "common.cuh")).read()
+    for const in ("0xB5297Bu", "0x9E3779u", "0x8DA6B5u", "0x3C6EF3u", "x >> 24", "x >> 15", "x >> 13", "x >> 11"):
+        assert const in cu[cu.index("uint2 dropout_quad("):cu.index("dropout_pair(")], const      # the emulation follows the kernel source
+    s = dh.structural(dh.quad, 167936)
+    assert s["duplicate_row_masks"] == 0 and s["duplicate_quad_frac"] < 0.01, s
+    assert dh.structural(dh.quad_r3, 167936)["duplicate_row_masks"] > 30000
+    st = dh.statistics(dh.quad, n=1 << 20)
+    assert all(abs(r - 0.0635) < 1.5e-3 for r in st["rates"]), st
+    assert st["cross_draw_worst"] < 6e-3 and st["key_bit_worst"] < 8e-3 and max(st["lag_worst"].values()) < 6e-3, st

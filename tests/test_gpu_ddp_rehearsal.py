@@ -18,7 +18,7 @@ import os, sys, torch
 sys.path.insert(0, os.environ["CP_ROOT"])
 from contrastiveprosthetics_amd import dist as cpdist, train
 a = train.build_parser().parse_args(["--crossval_load", "--final_epochs", "1", "--batch_size", "64", "--synthetic", "--no_adabn",
-                                     "--dtype", "f32", "--no_checkpoint", "--data_dir", os.environ["CP_OUT"],
+                                     "--dtype", os.environ["CP_DTYPE"], "--no_checkpoint", "--data_dir", os.environ["CP_OUT"],
                                      "--checkpoint_dir", os.environ["CP_OUT"]])
 train.args = a
 cpdist.init_from_env()
@@ -26,7 +26,7 @@ from contrastiveprosthetics_amd.load import DB23
 from contrastiveprosthetics_amd.utils import TaskWrapper
 torch.manual_seed(42)
 db = DB23(db2=False); db.load_synthetic(); db = TaskWrapper(db)
-params = dict(d_e=16, epochs=1, lr_emg=9.761e-4, reg_emg=7.103e-5, dp_emg=0.0, lr_glove=2.653e-3, reg_glove=2.840e-6, dp_glove=0.0)
+params = dict(d_e=16, epochs=1, lr_emg=9.761e-4, reg_emg=7.103e-5, dp_emg=float(os.environ["CP_DP"]), lr_glove=2.653e-3, reg_glove=2.840e-6, dp_glove=0.0)
 (vl, va), model = train.train_loop(db, params, checkpoint=False, verbose=False)
 sd = {k: v.cpu() for k, v in model.state_dict().items()}
 torch.save(dict(sd=sd, val=(vl, va), world=cpdist.world_size()), os.path.join(os.environ["CP_OUT"], f"rank{cpdist.rank()}.pt"))
@@ -34,11 +34,11 @@ cpdist.shutdown()
 """
 
 
-def run(nproc, out, port):
+def run(nproc, out, port, dtype="f32", dp=0.0):
     os.makedirs(out, exist_ok=True)
     script = os.path.join(out, "worker.py")
     open(script, "w").write(WORKER)
-    env = dict(os.environ, CP_ROOT=ROOT, CP_OUT=str(out), CP_DIST_BACKEND="gloo")
+    env = dict(os.environ, CP_ROOT=ROOT, CP_OUT=str(out), CP_DIST_BACKEND="gloo", CP_DTYPE=dtype, CP_DP=str(dp))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), script]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -64,3 +64,20 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     # the 2-rank job saw the same groups as the 1-rank job in a different batching: parameters moved comparably
     moved1 = sum(float((one["sd"][k] - r0["sd"][k]).abs().max()) for k in one["sd"] if one["sd"][k].dtype.is_floating_point)
     assert moved1 > 0.0
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_training_in_8_bits(tmp_path):
+    """the same rehearsal with --dtype fp8 and dropout on.  Each rank keeps its OWN scale table (its shard's
+    maxima) and draws its own dropout stream, so the ranks' local gradients differ -- but every rank applies the same all-reduced
+    gradient to the same broadcast parameters: the replicas must stay bit-identical, and the job must have learnt something."""
+    run(2, tmp_path / "two", 29743, dtype="fp8", dp=0.0635)
+    r0 = torch.load(tmp_path / "two" / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "two" / "rank1.pt", weights_only=True)
+    assert r0["world"] == r1["world"] == 2
+    for k, v in r0["sd"].items():
+        if "running" in k or "num_batches" in k:
+            continue
+        assert torch.isfinite(v).all(), k
+        assert torch.equal(v, r1["sd"][k]), k
+    assert 0.0 <= r0["val"][1] <= 1.0 and r0["val"][0] < 3.72          # (validation loss below its value at initialisation, 3.72)

@@ -166,7 +166,7 @@ def test_step_runs_and_learns():
 @pytest.mark.parametrize("B", [64, 5])
 def test_backward_8bit_against_the_bf16_bridge(dp, B):
     """the 8-bit backward kernels (e5m2 gradients, e4m3 activations and W^T) against the bf16 backward kernels run on the SAME
-    forward pass's tensors (cp_debug_set_option "fp8_bridge"): every parameter gradient by cosine and by norm.  What separates the two is the
+    forward pass's tensors (cp_config.options, CP_OPT_FP8_BRIDGE): every parameter gradient by cosine and by norm.  What separates the two is the
     rounding of the gradients between layers to two mantissa bits; a wrong lane map, scale or mask gives cosines near zero."""
     sd = nontrivial_sd(53, False)
     EMG = randn(505, (B, T, 1, 1, 12))
@@ -175,17 +175,14 @@ def test_backward_8bit_against_the_bf16_bridge(dp, B):
     grads = {}
     for mode in ("bridge", "native"):
         e = make_engine(sd, False, "fp8", dp=dp, seed=11)
-        e.lib.cp_debug_set_option(b"fp8_bridge", 1 if mode == "bridge" else 0)
-        try:
-            for _ in range(3):                     # (the third step runs with scales calibrated by the first two, gradients included)
-                e.step_count = 0                   # same dropout masks in every pass and in both modes
-                e.grads.flat.zero_()
-                z = e.encoder_forward(x, training=True)
-                out, pred, _ = e.head(z, label, 1, want_grad=True)
-                e.encoder_backward(x)
-            torch.cuda.synchronize()
-        finally:
-            e.lib.cp_debug_set_option(b"fp8_bridge", 0)
+        e.options["fp8_bridge"] = 1 if mode == "bridge" else 0          # (per engine: carried in its cp_config)
+        for _ in range(3):                     # (the third step runs with scales calibrated by the first two, gradients included)
+            e.step_count = 0                   # same dropout masks in every pass and in both modes
+            e.grads.flat.zero_()
+            z = e.encoder_forward(x, training=True)
+            out, pred, _ = e.head(z, label, 1, want_grad=True)
+            e.encoder_backward(x)
+        torch.cuda.synchronize()
         grads[mode] = {k: v.clone().cpu().double() for k, v in e.grads.views.items()}
         assert all(bool(torch.isfinite(v).all()) for v in grads[mode].values()), (mode, [k for k, v in grads[mode].items() if not torch.isfinite(v).all()])
     worst = (1.0, "")
@@ -270,14 +267,12 @@ def test_head_logits_on_the_8bit_mfma():
     z = e.encoder_forward(x, training=True).clone()
     res = {}
     for f32_head in (0, 1):
-        _lib.check(e.lib.cp_debug_set_option(b"fp8_head_f32", f32_head), "cp_debug_set_option")
-        try:
-            e.grads.flat.zero_()
-            out, pred, logits = e.head(z, labels, 1, want_grad=True, want_logits=True)
-            torch.cuda.synchronize()
-            res[f32_head] = (out.clone(), pred.clone(), logits.clone(), e.grads.views["glove_net.easy.0.weight"].clone())
-        finally:
-            e.lib.cp_debug_set_option(b"fp8_head_f32", 0)
+        e.options["fp8_head_f32"] = f32_head
+        e.grads.flat.zero_()
+        out, pred, logits = e.head(z, labels, 1, want_grad=True, want_logits=True)
+        torch.cuda.synchronize()
+        res[f32_head] = (out.clone(), pred.clone(), logits.clone(), e.grads.views["glove_net.easy.0.weight"].clone())
+    e.options["fp8_head_f32"] = 0
     (o8, p8, l8, g8), (o32, p32, l32, g32) = res[0], res[1]
     # the emulation: both unit vectors to e4m3, products and sums in f32
     zh = z / z.norm(dim=-1, keepdim=True)

@@ -133,7 +133,7 @@ def test_half_batches_bracket_full_batch_loss():
 # ---------------------------------------------------------------------------------------------------------------------
 # The BENCHMARKED configuration itself -- 4096 groups, bf16, stock BatchNorm (--no_adabn), dp_emg = 0.0635 -- held to an
 # independent fp32 recomputation, kernel by kernel.  Everything the bf16 step stores is read back
-# (activations, dropout outputs, BN statistics, and -- through cp_debug_set_grad_tap -- every intermediate gradient), and
+# (activations, dropout outputs, BN statistics, and -- through cp_config.grad_tap -- every intermediate gradient), and
 # each kernel's OUTPUT is recomputed with plain torch fp32 ops on the GPU from that kernel's own stored INPUTS, in the
 # reference's layer order Linear -> ReLU -> BN -> Dropout (code/models.py:266-298):
 #   forward : conv2 from x (conv1 + BN1 recomputed), fc1..fc7 and the projection from the stored input of each layer;
@@ -209,16 +209,13 @@ def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
     x = (mu_[None, :, :] + torch.randn(B, T, 12, generator=g_)).reshape(N, 12).cuda()
     labels = torch.arange(T).repeat(B).cuda()
     tap = torch.zeros(9, N, 768, dtype=torch.bfloat16, device="cuda")
-    lib = _lib.load()
-    _lib.check(lib.cp_debug_set_grad_tap(tap.data_ptr(), tap.numel() * 2), "cp_debug_set_grad_tap")
-    try:
-        e.grads.flat.zero_()
-        z = e.encoder_forward(x, training=True)
-        out, pred, _ = e.head(z, labels, 1, want_grad=True)
-        e.encoder_backward(x)
-        torch.cuda.synchronize()
-    finally:
-        lib.cp_debug_set_grad_tap(None, 0)
+    e.grad_tap = tap                                             # (cp_config.grad_tap of this engine's calls)
+    e.grads.flat.zero_()
+    z = e.encoder_forward(x, training=True)
+    out, pred, _ = e.head(z, labels, 1, want_grad=True)
+    e.encoder_backward(x)
+    torch.cuda.synchronize()
+    e.grad_tap = None
     W = e.values.views
     G = e.grads.views
     report = {}

@@ -1,5 +1,5 @@
 """bf16 backward with BatchNorm + ReLU backward applied in the data-gradient epilogue (the default where no dropout sits
-between two layers) against the same step with the separate in-place pass (cp_debug_set_option "unfused_bn_bwd").  The only arithmetic difference: the separate pass sees the incoming gradient rounded to bf16 first.
+between two layers) against the same step with the separate in-place pass (cp_config.options, CP_OPT_UNFUSED_BN_BWD).  The only arithmetic difference: the separate pass sees the incoming gradient rounded to bf16 first.
 40,000 rows = 157 sample tiles (ragged last tile); dp = 0 fuses all seven fc layers and conv2, dp > 0 only fc1..fc3 and
 conv2 (dropout follows fc4..fc7)."""
 import pytest
@@ -30,14 +30,11 @@ def test_bf16_fused_bn_backward_equals_separate_pass(dp):
                 if v.dim() == 1 and "linear" in k or "conv_emg.2" in k or "conv_emg.5" in k:
                     v.copy_((1.0 + 0.2 * torch.randn(v.shape, generator=gg) if k.endswith("weight") else 0.1 * torch.randn(v.shape, generator=gg)).cuda())
         e.grads.flat.zero_()
-        _lib.check(e.lib.cp_debug_set_option(b"unfused_bn_bwd", 1 if unfused else 0), "cp_debug_set_option")
-        try:
-            z = e.encoder_forward(x, training=True)
-            e.head(z, labels, 1, want_grad=True)
-            e.encoder_backward(x)
-            torch.cuda.synchronize()
-        finally:
-            e.lib.cp_debug_set_option(b"unfused_bn_bwd", 0)
+        e.options["unfused_bn_bwd"] = 1 if unfused else 0
+        z = e.encoder_forward(x, training=True)
+        e.head(z, labels, 1, want_grad=True)
+        e.encoder_backward(x)
+        torch.cuda.synchronize()
         assert torch.isfinite(e.grads.flat).all()
         grads.append({k: e.grads.views[k].clone() for k in e.specs})
     for k in grads[0]:
@@ -52,7 +49,7 @@ def test_bf16_fused_bn_backward_equals_separate_pass(dp):
 
 def test_paired_weight_gradients_equal_unpaired():
     """bf16 with dropout: the weight gradients of fc7/fc6 and fc5/fc4 run as two problems of one launch with 32 splits
-    each (api.hip, defer_wgrad) -- against one launch per layer with 64 splits (cp_debug_set_option "unpaired_wgrad").  Same products,
+    each (api.hip, defer_wgrad) -- against one launch per layer with 64 splits (cp_config.options, CP_OPT_UNPAIRED_WGRAD).  Same products,
     f32 partial sums grouped differently."""
     from contrastiveprosthetics_amd.engine import Engine
     n = 40000 - 40000 % T
@@ -65,14 +62,11 @@ def test_paired_weight_gradients_equal_unpaired():
         e = Engine(adabn=False, dtype="bf16", dp_emg=0.0635, device="cuda", seed=123)
         e.init_parameters(8)
         e.grads.flat.zero_()
-        _lib.check(e.lib.cp_debug_set_option(b"unpaired_wgrad", 1 if unpaired else 0), "cp_debug_set_option")
-        try:
-            z = e.encoder_forward(x, training=True)
-            e.head(z, labels, 1, want_grad=True)
-            e.encoder_backward(x)
-            torch.cuda.synchronize()
-        finally:
-            e.lib.cp_debug_set_option(b"unpaired_wgrad", 0)
+        e.options["unpaired_wgrad"] = 1 if unpaired else 0
+        z = e.encoder_forward(x, training=True)
+        e.head(z, labels, 1, want_grad=True)
+        e.encoder_backward(x)
+        torch.cuda.synchronize()
         grads.append({k: e.grads.views[k].clone() for k in e.specs})
     from contrastiveprosthetics_amd.engine import LINEAR_IDX
     behind_dropout = {f"emg_net.linear.{LINEAR_IDX[i]}.weight" for i in (4, 5, 6)} | {"emg_net.last.0.weight"}

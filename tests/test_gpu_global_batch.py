@@ -1,5 +1,5 @@
 """SURVEY 8e extensions on the real kernels: --global_negatives (cp_global_negatives + cp_head_gneg) against the oracle's
-definition, and --sync_bn (cp_set_stats_allreduce) as "2 ranks x B/2 groups == 1 rank x B groups".  The GPU box has one card:
+definition, and --sync_bn (cp_config.stats_allreduce) as "2 ranks x B/2 groups == 1 rank x B groups".  The GPU box has one card:
 the two ranks share it and the collectives go through gloo, as in test_gpu_ddp_rehearsal.py; what is checked is the arithmetic
 of the sharded path, not RCCL."""
 import os
@@ -236,3 +236,25 @@ def test_sync_bn_two_ranks_equal_the_whole_batch_at_the_device_masks(tmp_path):
     for k, v in one["running"].items():
         if v.dtype.is_floating_point:
             np.testing.assert_allclose(two["running"][k].numpy(), v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.timeout(900)
+def test_sync_bn_in_8_bits_two_ranks_equal_one(tmp_path):
+    """synchronised BatchNorm wired into the 8-bit path (round 3 returned CP_ERR_ARG).  Every rank stores its
+    activations with its OWN power-of-two scale, so the statistics rows cross the ranks in TRUE units (colsum_finalize_kernel's
+    unscale): 2 ranks x 24 groups == 1 rank x 48 groups -- running statistics to 1e-3, embeddings to 2 % rms (an element whose value
+    sits on an e4m3 rounding boundary may round the other way when a statistic moves in its last bit), the averaged gradient by cosine."""
+    B = 48
+    _run(2, tmp_path, 29753, B, "fp8")
+    _run(1, tmp_path, 29754, B, "fp8")
+    two = torch.load(tmp_path / "w2.pt", weights_only=True)
+    one = torch.load(tmp_path / "w1.pt", weights_only=True)
+    for k, v in one["running"].items():
+        if v.dtype.is_floating_point:
+            np.testing.assert_allclose(two["running"][k].numpy(), v.numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+    dz = (two["z"] - one["z"]).pow(2).mean().sqrt() / one["z"].pow(2).mean().sqrt()
+    a, b = two["grads"].double(), one["grads"].double()
+    cos = float(a @ b / (a.norm() * b.norm()))
+    print(f"fp8 sync BN, 2 ranks vs 1: relative rms dz {float(dz):.3e}, gradient cosine {cos:.5f}, loss {two['loss'].item():.5f} vs {one['loss'].item():.5f}")
+    assert float(dz) < 2e-2 and cos > 0.97
+    assert two["loss"].item() == pytest.approx(one["loss"].item(), rel=2e-3)

@@ -1,5 +1,5 @@
 """The small-batch path (csrc/small.cuh: up to 64 groups = 2624 windows, the reference's own batch sizes, code/train.py:185) against
-the large-batch kernels on the same inputs (cp_debug_set_option "no_small"), one whole training step: z, loss, BatchNorm running
+the large-batch kernels on the same inputs (cp_config.options, CP_OPT_NO_SMALL), one whole training step: z, loss, BatchNorm running
 statistics and every gradient.  The two paths compute the same sums in different groupings (the small path's BatchNorm totals are
 fixed-point integers, its weight gradients whole-batch or 2..8 row splits; its data gradients carry BatchNorm + ReLU backward in the
 staging of the NEXT launch instead of an epilogue).
@@ -42,15 +42,12 @@ def _step(dtype, groups, no_small, dp=0.0635):
                                                                                        k.split(".")[-2] in ("2", "5", "8", "11", "15", "19", "23")):
             v.copy_((1.0 + 0.2 * torch.randn(v.shape, generator=gg) if k.endswith("weight") else 0.1 * torch.randn(v.shape, generator=gg)).cuda())
     e.grads.flat.fill_(float("nan"))
-    _lib.check(e.lib.cp_debug_set_option(b"no_small", 1 if no_small else 0), "cp_debug_set_option")
-    try:
-        z = e.encoder_forward(x, training=True).clone()
-        out, _, _ = e.head(z, labels, 1, want_grad=True)
-        e.encoder_backward(x)
-        torch.cuda.synchronize()
-        act8 = e.debug_activation(8)                         # fc7's stored output relu(.)
-    finally:
-        e.lib.cp_debug_set_option(b"no_small", 0)
+    e.options["no_small"] = 1 if no_small else 0
+    z = e.encoder_forward(x, training=True).clone()
+    out, _, _ = e.head(z, labels, 1, want_grad=True)
+    e.encoder_backward(x)
+    torch.cuda.synchronize()
+    act8 = e.debug_activation(8)                         # fc7's stored output relu(.)
     grads = {k: e.grads.views[k].clone() for k in e.specs if k.startswith("emg_net.") or k.startswith("glove_net.easy.")}
     running = {k: v.clone() for k, v in e.running.items() if torch.is_tensor(v) and v.is_floating_point()}
     return z, out.clone(), grads, running, act8
@@ -95,3 +92,37 @@ def test_small_batch_step_is_bit_exact_run_to_run(dtype):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for k in a[2]:
         assert torch.equal(a[2][k], b[2][k]), k
+
+
+@pytest.mark.parametrize("no_small", [False, True])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_backward_twice_over_one_forward(dtype, no_small):
+    """the small-batch form's BatchNorm-backward totals are fixed-point atomics zeroed by the FORWARD's preparation launch, so a
+    second cp_encoder_backward over the same forward (gradient checks, timing the backward alone, C-ABI callers) used to add onto the
+    first pass's sums.  The library now knows (per workspace) that it is a repeat and zeroes them first: both passes give the same
+    gradients, bit for bit, on either kernel path; and a backward whose configuration differs from its forward's is refused."""
+    from contrastiveprosthetics_amd.engine import Engine
+    groups = 16
+    n = groups * T
+    g = torch.Generator().manual_seed(23)
+    x = (torch.randn(T, 12, generator=g)[None] + torch.randn(groups, T, 12, generator=g)).reshape(n, 12).cuda()
+    labels = torch.arange(T).repeat(groups).cuda()
+    e = Engine(adabn=False, dtype=dtype, dp_emg=0.0635, device="cuda", seed=3)
+    e.options["no_small"] = 1 if no_small else 0
+    e.init_parameters(7)
+    z = e.encoder_forward(x, training=True)
+    e.head(z, labels, 1, want_grad=True)
+    e.grads.flat.fill_(float("nan"))
+    e.encoder_backward(x)
+    first = e.grads.flat.clone()
+    e.grads.flat.fill_(float("nan"))
+    e.encoder_backward(x)
+    torch.cuda.synchronize()
+    emg = torch.cat([e.grads.views[k].reshape(-1) for k in e.specs if k.startswith("emg_net.")])
+    emg1 = torch.cat([first[o:o + m] for k, (o, m) in e.grads.offsets.items() if k.startswith("emg_net.")])
+    assert torch.isfinite(emg).all()
+    assert torch.equal(emg, emg1)
+    # the other path's backward over this forward is an error, not a silent mix of two workspace layouts
+    e.options["no_small"] = 0 if no_small else 1
+    with pytest.raises(_lib.CpNativeError):
+        e.encoder_backward(x)

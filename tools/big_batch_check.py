@@ -10,7 +10,7 @@ for groups, sched in ((8192, 0), (8192, 1), (12001, 0)):
     x = (mu[None] + torch.randn(groups, T, 12, generator=g)).reshape(n, 12).cuda()
     labels = torch.arange(T).repeat(groups).cuda()
     e = Engine(adabn=False, dtype="bf16", dp_emg=0.0635, device="cuda", seed=123)
-    e.lib.cp_set_tile_schedule(sched)
+    e.tile_schedule = sched
     e.init_parameters(5)
     e.grads.flat.zero_()
     z = e.encoder_forward(x, training=True)
@@ -20,6 +20,6 @@ for groups, sched in ((8192, 0), (8192, 1), (12001, 0)):
     fin = all(torch.isfinite(v).all() for k, v in e.grads.views.items() if k.startswith("emg_net."))
     print(groups, "groups", n, "windows, schedule", sched, "loss", float(out[0]), "acc", float(out[1]) / n, "finite grads", fin,
           "|g|", float(e.grads.flat.norm()))
-    e.lib.cp_set_tile_schedule(0)
+    e.tile_schedule = 0
     del e, x, z
     torch.cuda.empty_cache()

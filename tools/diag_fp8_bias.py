@@ -14,12 +14,12 @@ lib=_lib.load()
 for it in range(3):
     e.step_count=0
     e.grads.flat.zero_()
-    if it==2: lib.cp_debug_set_grad_tap(tap.data_ptr(), tap.numel()*2)
+    if it==2: e.grad_tap = tap
     z = e.encoder_forward(x, training=True)
     e.head(z, labels, 1, want_grad=True)
     e.encoder_backward(x)
     torch.cuda.synchronize()
-lib.cp_debug_set_grad_tap(None,0)
+e.grad_tap = None
 ex = e.fp8_scale_exponents()
 print("exps act", ex[1:12].tolist(), "grad", ex[16:25].tolist(), "gb", ex[32:41].tolist())
 LIN=(0,3,6,9,13,17,21)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Steps per second of the training step at the reference's own batch sizes, issued call by call and replayed as one HIP
 graph (engine.GraphStep).  usage: python tools/graph_bench.py [batch ...]   (default 8 32 64 128)
-CP_GB_DTYPE=f32|bf16 (default bf16); CP_GB_NO_SMALL=1: batches of <= 64 groups on the large-batch kernels (cp_debug_set_option "no_small")."""
+CP_GB_DTYPE=f32|bf16 (default bf16); CP_GB_NO_SMALL=1: batches of <= 64 groups on the large-batch kernels (cp_config.options, CP_OPT_NO_SMALL)."""
 import os
 import sys
 import time
@@ -24,7 +24,7 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128]:
     res = {}
     for mode in ("calls", "graph"):
         e = Engine(adabn=False, dtype=DT, dp_emg=BEST["dp_emg"], device="cuda", seed=1)
-        e.lib.cp_debug_set_option(b"no_small", 1 if os.environ.get("CP_GB_NO_SMALL") else 0)
+        e.options["no_small"] = 1 if os.environ.get("CP_GB_NO_SMALL") else 0
         e.init_parameters(2)
         gs = GraphStep(e, table, emg_rand, B, BEST) if mode == "graph" else None
 

@@ -19,7 +19,7 @@ table = (torch.randn(T, 1, 12, generator=g) + torch.randn(T, D, 12, generator=g)
 emg_rand = (torch.rand(T, D, generator=g).argsort(-1) + torch.arange(T).reshape(T, 1) * D).cuda()
 labels = torch.arange(T).repeat(B).cuda()
 e = Engine(adabn=False, dtype=DT, dp_emg=BEST["dp_emg"], device="cuda", seed=1)
-e.lib.cp_debug_set_option(b"no_small", 1 if "no_small" in sys.argv else 0)
+e.options["no_small"] = 1 if "no_small" in sys.argv else 0
 e.init_parameters(2)
 for s in range(12):
     p = torch.randperm(D, generator=g)[:B].cuda()
