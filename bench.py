@@ -9,12 +9,12 @@ One step = one full optimisation step of code/train.py:95-108 on one batch of sy
 Ninapro-shaped windows already resident in HBM: group gather -> EMG encoder forward ->
 (N>1: RCCL all-gather of the z embeddings, read by the global-negatives column loss) -> class encoder +
 41x41 logits + symmetric CE -> backward -> (N>1: RCCL all-reduce of the 8 MB flat gradient) -> L2 regulariser + 2 x Adam.
-N = 1 is BASELINE config[1] with the reference's per-group loss and no collective.  N > 1 is config[2] ("global batch
+N = 1 is BASELINE.json configs[1] with the reference's per-group loss and no collective.  N > 1 is configs[2] ("global batch
 ... with RCCL z all-gather"): the gathered z matrix feeds the global-negatives extension of the class->EMG direction
 (cp_global_negatives + cp_head_gneg, the same code path as train.py --global_negatives); --global_negatives off drops
 the collective and the extension, on forces them at N = 1 (where the "gathered" matrix is the rank's own z).
-Workload at every N: BASELINE config[1] per GPU ("synthetic 12-ch sEMG, 41-class one-hot, batch
-4096, bf16"): 4096 groups = 167,936 windows per GPU per step (weak scaling; config[2] is N=8).
+Workload at every N: BASELINE.json configs[1] per GPU ("synthetic 12-ch sEMG, 41-class one-hot, batch
+4096, bf16"): 4096 groups = 167,936 windows per GPU per step (weak scaling; configs[2] is N=8).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live, inside the timed region, with HIP
 events recorded by the library on the stream the kernels run on (cp_profile_*); `cpu_baseline` is
@@ -135,7 +135,7 @@ def measure_practical_peaks(dev, dtype):
 def cpu_baseline(seconds: float, threads: int):
     """The reference step on host cores: oracle (pure torch CPU restatement: per-item gather, 3x3
     Conv2d, per-group CE loop, separate norms, 2 x Adam).  Headline = B=64 groups (its best CPU batch, SURVEY 6);
-    `b8` = BASELINE config 1's own batch size (8 groups), about a third of the sample time.  The port's step time is
+    `b8` = BASELINE.json configs[0]'s own batch size (8 groups), about a third of the sample time.  The port's step time is
     held to the imported reference's in the build container by tools/time_port_vs_reference.py
     (profiles/r02_port_vs_reference.json: within 10 % at both sizes)."""
     from oracle import ref_cpu as oc
@@ -172,7 +172,7 @@ def cpu_baseline(seconds: float, threads: int):
     big = run(64, seconds * 2.0 / 3.0)
     small = run(8, seconds / 3.0)
     return dict(value=big["value"], unit="windows/s", cores=threads, kind="port", sample=big["sample"],
-                b8=dict(small, cores=threads, note="BASELINE config 1 batch size (train.py --batch_size 8 --no_adabn)"))
+                b8=dict(small, cores=threads, note="BASELINE.json configs[0] batch size (train.py --batch_size 8 --no_adabn)"))
 
 
 def small_batch_record(dev, dtype: str, seconds: float = 0.6):
@@ -213,6 +213,114 @@ def small_batch_record(dev, dtype: str, seconds: float = 0.6):
     return out
 
 
+def _side_failed(rec_key, rec, ex, dev):
+    """A side record failed: it never costs the line its main measurement -- unless the device itself is in an error state (a sticky
+    hipError would make every later number meaningless): then the run ends non-zero instead of printing a line."""
+    rec[rec_key] = dict(error=f"{type(ex).__name__}: {ex}")
+    try:
+        torch.cuda.synchronize(dev)
+    except Exception as ex2:
+        print(f"bench.py: device error after the {rec_key} side record ({ex2}); aborting without a result line", file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
+def _time_steps(fn, n_warm, n_timed, dev):
+    for i in range(n_warm):
+        fn(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(n_timed):
+        fn(n_warm + i)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / n_timed
+
+
+def eval_record(dev, dtypes, groups=160, V=25, steps=10):
+    """The product's use-case (/root/reference/code/train.py:27-63, code/models.py:138-163): a validate()/test()-shaped
+    pass -- gather of `groups` x 41 x V windows (V = 25 consecutive samples per window group), encoder forward in eval mode (stock BN:
+    running statistics), 41 x 41 logits + loss + argmax for the groups x V sample groups, the 25-sample majority vote (cp_vote) and the
+    class-subset restriction (cp_subset_vote over 64 random subsets) -- inputs resident, timed call by call.  Forward-only byte model:
+    every one of the 9 stored activations written once and read once by the next layer (2 x 5,120 elements per window; the eval
+    forward runs the training kernels, i.e. does NOT fold the running statistics across layers), 4.25 MFLOP per window."""
+    from contrastiveprosthetics_amd import engine as E
+    from contrastiveprosthetics_amd.engine import Engine
+    D = 2000                                                     # test-mode table: D rows of 25 consecutive samples per class
+    g = torch.Generator().manual_seed(11)
+    table = (torch.randn(T, 1, 1, 12, generator=g) + torch.randn(T, D, V, 12, generator=g)).reshape(T * D * V, 12).to(dev)
+    emg_rand = (torch.rand(T, D, generator=g).argsort(-1) + torch.arange(T).reshape(T, 1) * D).to(dev)
+    labels = torch.arange(T).repeat(groups).to(dev)
+    masks = (torch.rand(64, T, generator=g) < 0.5).to(torch.uint8)
+    masks[:, 0] = 1
+    perms = [torch.randperm(D, generator=g)[:groups].to(dev) for _ in range(steps + 3)]
+    n = groups * T * V
+    out = dict(groups=groups, V=V, windows=n, note="gather + eval forward + head + cp_vote + cp_subset_vote (64 subsets), stock BN running statistics, "
+               "call by call; forward-only model: 2 x 5,120 stored elements and 4.25 MFLOP per window")
+    for dt in dtypes:
+        e = Engine(adabn=False, dtype=dt, dp_emg=BEST["dp_emg"], device=dev, seed=3)
+        e.init_parameters(2)
+        xw = e.gather(table, emg_rand, perms[0], V)
+        for _ in range(2):                                       # running statistics (and, in 8 bits, scales) from two training-mode passes
+            e.encoder_forward(xw, training=True)
+        parts = {}
+
+        def one(i, parts=parts, e=e):
+            x = e.gather(table, emg_rand, perms[i], V)
+            z = e.encoder_forward(x, training=False)
+            o, pred, logits = e.head(z, labels, V, want_grad=False, want_logits=True)
+            curve, y_pred = e.vote(pred, labels, groups, V)
+            E.subset_vote(logits, labels[:T].contiguous(), groups, V, masks)
+            parts["o"] = o
+        sec = _time_steps(one, 3, steps, dev)
+
+        def fwd_only(i, e=e, xw=xw):
+            e.encoder_forward(xw, training=False)
+        sec_f = _time_steps(fwd_only, 2, steps, dev)
+        es = {"f32": 4, "bf16": 2, "fp8": 1}[dt]
+        byts = n * (2 * 5120 * es + 48 + 64)
+        out[dt] = dict(ms=sec * 1e3, windows_per_s=n / sec, forward_ms=sec_f * 1e3, loss=float(parts["o"][0]),
+                       roofline=dict(bound="hbm" if dt != "f32" else "mfma", algorithmic_bytes=byts, achieved=byts / sec_f / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                     frac=byts / sec_f / 1e9 / HBM_PEAK_GBS, mfma_tflops=4.249e6 * n / sec_f / 1e12,
+                                     mfma_frac=4.249e6 * n / sec_f / 1e12 / MFMA_PEAK_TFLOPS[dt], scope="encoder forward alone (forward_ms)"))
+        del e
+    return out
+
+
+def glove_record(dev, dtype, B, table, emg_rand, perms, labels, steps):
+    """BASELINE.json configs[3] (0-based, as everywhere in this repo; SURVEY 8 counts the same list from 1: "cfg4"): the same training step with the glove-angle (20-dim) class encoder instead of the one-hot
+    table (cp_glove_forward / cp_head_glove / cp_glove_backward), timed in the run of the default line.  Its own full line:
+    python bench.py --class_encoder glove."""
+    from contrastiveprosthetics_amd.engine import Engine
+    g = torch.Generator().manual_seed(77)
+    gm = torch.randn(T, 20, generator=g)
+    rows = (gm[None] + 0.3 * torch.randn(B, T, 20, generator=g)).to(dev)
+    e = Engine(adabn=False, dtype=dtype, dp_emg=BEST["dp_emg"], device=dev, seed=1000, class_encoder="glove")
+    e.init_parameters(seed=42)
+    e.workspace(B * T)
+    res = {}
+
+    def one(i):
+        x = e.gather(table, emg_rand, perms[i % len(perms)], 1)
+        z = e.encoder_forward(x, training=True)
+        zg = e.glove_forward(rows, training=True)
+        o, _, _ = e.head_glove(z, zg, labels, 1, want_grad=True)
+        e.glove_backward()
+        e.encoder_backward(x)
+        e.adam_step(BEST)
+        res["o"] = o
+    sec = _time_steps(one, 4, steps, dev)
+    # the class encoder's own launches, timed alone on the same engine
+    def glove_only(i):
+        zg = e.glove_forward(rows, training=True)
+        e.glove_backward()
+    z = e.encoder_forward(e.gather(table, emg_rand, perms[0], 1), training=True)
+    e.head_glove(z, e.glove_forward(rows, training=True), labels, 1, want_grad=True)
+    sec_g = _time_steps(glove_only, 2, steps, dev)
+    return dict(ms_per_step=sec * 1e3, value=B * T / sec, unit="windows/s", steps=steps, loss=float(res["o"][0]), dtype=dtype,
+                glove_forward_backward_ms=sec_g * 1e3,
+                note="configs[3]: glove-angle class encoder (Linear(20,256) -> BN -> ReLU -> Linear(256,16), code/models.py:386-391,425-428,460-461); "
+                     "parity unpinned (the reference keeps these layers as comments)")
+
+
 def _timed_mode(mode, k_other, step, barrier, args, use_dist, dist, dev, world, N):
     """ms per step of the training step under another loss workload (bench.py `other_steps`)."""
     for i in range(2):
@@ -239,7 +347,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch_size", type=int, default=4096, help="groups of 41 windows per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
-    ap.add_argument("--adabn", action="store_true", help="AdaBN instead of stock BN (--no_adabn is BASELINE config 1)")
+    ap.add_argument("--adabn", action="store_true", help="AdaBN instead of stock BN (--no_adabn is what BASELINE.json configs[0] runs)")
     ap.add_argument("--dp_emg", type=float, default=BEST["dp_emg"])
     ap.add_argument("--cpu_seconds", type=float, default=15.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -249,14 +357,14 @@ def main():
     ap.add_argument("--profile_every", type=int, default=20,
                     help="bracket the fc GEMM launches with HIP events (the live roofline numbers) on every n-th timed step")
     ap.add_argument("--global_negatives", default="auto", choices=["auto", "on", "gather", "reduce", "off"],
-                    help="auto: gather when N > 1 (BASELINE config[2] names the z all-gather; it must have a reader), off at N = 1 (config[1]: "
+                    help="auto: gather when N > 1 (BASELINE.json configs[2] names the z all-gather; it must have a reader), off at N = 1 (configs[1]: "
                          "the reference's per-group loss).  on = gather.  reduce: the same {G, H} table from per-rank partial sums and two "
                          "64-float all-reduces (cp_global_negatives_g / _h): no z moves.  Whatever is chosen, the line also carries the "
                          "other workloads' step times from a second, shorter timed region (`other_steps`), so that the N = 1 and N > 1 "
                          "lines of a scaling run hold one workload between them")
     ap.add_argument("--sync_bn", action="store_true", help="BatchNorm statistics over the global batch (18 small all-reduces per step)")
     ap.add_argument("--class_encoder", default="onehot", choices=["onehot", "glove"],
-                    help="glove = BASELINE config 3 (glove-angle class encoder); the default line is config 1 (one-hot)")
+                    help="glove = BASELINE.json configs[3] (glove-angle class encoder); the default line is configs[1] (one-hot)")
     args = ap.parse_args()
     if args.main_only:
         args.no_cpu_baseline = True
@@ -394,10 +502,26 @@ def main():
         for mode in ("off", "gather", "reduce"):
             if mode == gn or "error" in other_steps:
                 continue
+            ok = 1
             try:
                 other_steps[mode] = _timed_mode(mode, k_other, step, barrier, args, use_dist, dist, dev, world, N)
             except Exception as ex:                           # the side records never cost the line its main measurement
                 other_steps["error"] = f"{mode}: {type(ex).__name__}: {ex}"
+                ok = 0
+            if use_dist:
+                # every rank must leave the side records together: a rank that went on alone would wait in the next mode's
+                # collectives for ranks that have stopped.  A rank that failed INSIDE a collective cannot be rescued
+                # here -- the process group's timeout ends such a run -- but a failure before or after one is agreed on.
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    other_steps.setdefault("error", f"{mode}: failed on another rank")
+            if "error" in other_steps:
+                try:
+                    torch.cuda.synchronize(dev)
+                except Exception as ex2:
+                    print(f"bench.py: device error after other_steps ({ex2}); aborting", file=sys.stderr, flush=True)
+                    sys.exit(3)
 
     if args.breakdown and rank == 0:
         eng.profile_enable(None, max_records=4096)
@@ -492,7 +616,7 @@ def main():
             rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
         if world == 1 and not rehearse and args.class_encoder == "onehot" and not args.main_only and args.dtype == "bf16":
             try:
-                # BASELINE config 4's storage on the same workload, same run (its own line: python bench.py --dtype fp8): 8-bit activations,
+                # BASELINE.json configs[4]'s storage on the same workload, same run (its own line: python bench.py --dtype fp8): 8-bit activations,
                 # weights and gradients on the block-scaled MFMA.  Parity unpinned by construction; it is not `value`.
                 e8 = Engine(adabn=args.adabn, dtype="fp8", dp_emg=args.dp_emg, device=dev, seed=1000)
                 e8.init_parameters(seed=42)
@@ -515,17 +639,29 @@ def main():
                 torch.cuda.synchronize(dev)
                 el8 = time.perf_counter() - t8
                 rec["config4_fp8"] = dict(ms_per_step=1e3 * el8 / k8, value=N * k8 / el8, unit="windows/s", steps=k8, loss=float(o8[0]),
-                                          note="same workload with 8-bit storage + MX MFMA (CP_FP8), parity unpinned by construction; full line: bench.py --dtype fp8")
+                                          note="BASELINE.json configs[4] (0-based) per GPU at this batch: the same workload with 8-bit storage + MX MFMA (CP_FP8), "
+                                               "parity unpinned by construction; full line: bench.py --dtype fp8")
                 del e8
             except Exception as ex:                       # a side record: never at the cost of the line
-                rec["config4_fp8"] = dict(error=f"{type(ex).__name__}: {ex}")
+                _side_failed("config4_fp8", rec, ex, dev)
         if world == 1 and not rehearse and args.class_encoder == "onehot" and not args.main_only:
             try:
                 rec["small_batch"] = small_batch_record(dev, args.dtype)
                 if "cpu_baseline" in rec and "b8" in rec["cpu_baseline"]:
                     rec["small_batch"]["b8"]["over_cpu_b8"] = rec["small_batch"]["b8"]["windows_per_s"] / rec["cpu_baseline"]["b8"]["value"]
             except Exception as ex:
-                rec["small_batch"] = dict(error=f"{type(ex).__name__}: {ex}")
+                _side_failed("small_batch", rec, ex, dev)
+        if world == 1 and not rehearse and args.class_encoder == "onehot" and not args.main_only and args.dtype == "bf16" and B == 4096:
+            try:
+                rec["config3_glove"] = glove_record(dev, args.dtype, B, table, emg_rand, perms, labels, max(5, args.steps // 2))
+                rec["config3_glove"]["over_onehot_ms"] = rec["config3_glove"]["ms_per_step"] - rec["ms_per_step"]
+            except Exception as ex:
+                _side_failed("config3_glove", rec, ex, dev)
+        if world == 1 and not rehearse and not args.main_only:
+            try:
+                rec["eval"] = eval_record(dev, ["f32", "bf16", "fp8"] if args.dtype == "bf16" else [args.dtype])
+            except Exception as ex:
+                _side_failed("eval", rec, ex, dev)
         print(json.dumps(rec), flush=True)
     if use_dist:
         dist.destroy_process_group()

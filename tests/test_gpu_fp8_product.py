@@ -48,9 +48,11 @@ def _train_and_test(dtype, tmp_path, adabn_flag, epochs=3, batch=32):
 def test_train_validate_test_in_f32_bf16_fp8(tmp_path, capsys, adabn_flag):
     """the go.sh recipe (synthetic DB23, 3 epochs, --test) in the three storage types, both BatchNorm flavours.
     Asserted: every path learns (test accuracy far above the 1/41 chance level); the 8-bit path's final TEST ACCURACY (the 25-sample
-    majority vote over all 41 classes, code/models.py:151-163) and every column of its vote-length curve lie within 0.05 of the f32
-    path's (bf16: 0.04) -- one seed each, 48 test groups x 41 rows = 1,968 votes, so the binomial noise of a single accuracy figure is
-    ~0.011 and of a difference ~0.015: the margin is three sigma of that plus what a different rounding does to a 170-step trajectory."""
+    majority vote over all 41 classes, code/models.py:151-163) and every column of its vote-length curve lie within 0.02 of the f32
+    path's (bf16 likewise) -- one seed each, 48 test groups x 41 rows = 1,968 votes; the models are trained independently (a different
+    rounding changes a 170-step trajectory), so the margin is a few sigma of the binomial noise of an accuracy near 0.99 (0.002) and,
+    for the short-vote columns near 0.70, of 0.010.  Measured (round 4, MI355X): test accuracy f32 0.9909 / bf16 0.9888 / fp8 0.9929 (stock
+    BN), 0.9893 / 0.9888 / 0.9903 (AdaBN); largest vote-curve difference 0.007."""
     res = {}
     for dt in ("f32", "bf16", "fp8"):
         res[dt] = _train_and_test(dt, tmp_path, adabn_flag)
@@ -66,11 +68,11 @@ def test_train_validate_test_in_f32_bf16_fp8(tmp_path, capsys, adabn_flag):
     assert "Checkpointing model" in out
     for dt, (_, (tl, ta), vote, _, _) in res.items():
         assert np.isfinite(tl) and ta > 0.25, (dt, tl, ta)             # chance = 0.024
-    for dt, margin in (("bf16", 0.04), ("fp8", 0.05)):
+    for dt, margin in (("bf16", 0.02), ("fp8", 0.02)):
         assert abs(res[dt][1][1] - res["f32"][1][1]) <= margin, (dt, res[dt][1], res["f32"][1])
         dv = np.abs(res[dt][2].mean(0) - res["f32"][2].mean(0))
         assert dv.max() <= margin, (dt, dv)
-        assert abs(res[dt][1][0] - res["f32"][1][0]) <= 0.06, (dt, res[dt][1][0], res["f32"][1][0])      # test loss (CE floor 1.858)
+        assert abs(res[dt][1][0] - res["f32"][1][0]) <= 0.01, (dt, res[dt][1][0], res["f32"][1][0])      # test loss (CE floor 1.858)
 
 
 def test_fp8_checkpoint_round_trip_through_results(tmp_path, capsys):
@@ -204,7 +206,12 @@ def test_scale_table_survives_reallocation():
     # evaluation moved the activation scales by at most one binade from where training left them (same data distribution), and did
     # not touch the gradient scales (no backward ran)
     assert int((after[1:12] - before[1:12]).abs().max()) <= 1, (before[1:12], after[1:12])
-    assert torch.equal(after[16:25], before[16:25]) and torch.equal(after[32:41], before[32:41])
+    # the gradient scales: the first evaluation pass still consumes the maxima the LAST training step's backward left (at most one
+    # binade), after that they rest -- no backward runs
+    assert int((after[16:25] - before[16:25]).abs().max()) <= 1 and int((after[32:41] - before[32:41]).abs().max()) <= 1
+    z = e.encoder_forward(xe, training=False)
+    again = e.fp8_scale_exponents()
+    assert torch.equal(again[16:25], after[16:25]) and torch.equal(again[32:41], after[32:41])
 
 
 def test_fp8_with_the_glove_class_encoder():
