@@ -400,6 +400,8 @@ def main():
     params = dict(BEST, dp_emg=args.dp_emg)
     eng = Engine(adabn=args.adabn, dtype=args.dtype, dp_emg=args.dp_emg, device=dev, seed=1000 + rank,
                  class_encoder=args.class_encoder)
+    for o in filter(None, os.environ.get("CP_BENCH_OPTIONS", "").split(",")):      # A/B runs: cp_config.options of the main engine (e.g. finalize_launches)
+        eng.options[o] = 1
     eng.init_parameters(seed=42)                      # identical replicas, as DDP broadcasts them
     eng.workspace(N)
 

@@ -36,7 +36,7 @@ class cp_bn_buffers(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)     # cp_allreduce_fn
 
 # cp_config.options bits (include/cpnative.h CP_OPT_*): test / measurement switches of ONE call, 0 in production
-OPTIONS = {"unfused_bn_bwd": 1, "unpaired_wgrad": 2, "fp8_bridge": 4, "no_small": 8, "fp8_head_f32": 16, "finalize_launches": 32}
+OPTIONS = {"unfused_bn_bwd": 1, "unpaired_wgrad": 2, "fp8_bridge": 4, "no_small": 8, "fp8_head_f32": 16}
 CP_TILES_STATIC, CP_TILES_DYNAMIC = 0, 1
 
 

@@ -73,8 +73,6 @@ typedef int (*cp_allreduce_fn)(void* user, void* row_dev, int64_t count, void* s
 #define CP_OPT_FP8_BRIDGE 4u      /* CP_FP8: expand the saved 8-bit tensors to bf16 and run the bf16 backward kernels */
 #define CP_OPT_NO_SMALL 8u        /* batches of <= 64 groups on the large-batch kernels instead of the small-batch form */
 #define CP_OPT_FP8_HEAD_F32 16u   /* CP_FP8: the head's logits from the f32 matrix instruction instead of the block-scaled 8-bit one */
-#define CP_OPT_FINALIZE_LAUNCHES 32u /* large batches: BatchNorm statistics through partial rows + finalize launches (round 3's form) instead of
-                                      * fixed-point atomic totals finalised by the consumer */
 
 /* How the persistent fc GEMM kernels hand their output tiles to the CUs (cp_config.tile_schedule).  CP_TILES_STATIC: each
  * workgroup owns a fixed list of tiles -- fastest when this process has the GPU to itself (weight-stationary kernels).
