@@ -772,7 +772,7 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
 }
 
 template <typename T> static int conv_backward_tail(const cp_config*, const cp_params*, const float*, unsigned char*, const WS&, cp_params*, hipStream_t,
-                                                    hipEvent_t, T*, T*, bool, int, bool coef_ready = false);
+                                                    hipEvent_t, T*, T*, bool, int);
 
 template <typename T>
 static int encoder_backward_small_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
@@ -1325,7 +1325,7 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
 // pre-activation) when bn_done, as [N][768] == [(N*12)][64] T; nxt = scratch of the same size
 template <typename T>
 static int conv_backward_tail(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
-                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows, bool coef_ready) {
+                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows) {
     using D = DT<T>;
     const int64_t N = c->n_windows, R12 = N * 12;
     float* partials = (float*)(base + w.partials);
@@ -1355,11 +1355,8 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
         if (!bn_done) {
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
-            const float* pp = nullptr;
-            if (!coef_ready) {           // (else: the coefficients came with the sums, bn_bwd_from_wgrad_kernel)
-                pp = pre(nr, 2 * 768);
-                if (int e = bwd_finalize(pp, nr, (double)R12, 1, 64, 12, "bn_bwd_finalize_kernel(conv2)")) return e;
-            }
+            const float* pp = pre(nr, 2 * 768);
+            if (int e = bwd_finalize(pp, nr, (double)R12, 1, 64, 12, "bn_bwd_finalize_kernel(conv2)")) return e;
             const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
             nr = gb;
@@ -1462,18 +1459,6 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     T* cur = (T*)(base + w.gbuf[0]);
     T* nxt = (T*)(base + w.gbuf[1]);
     bool bn_done = false;           // (see the comment above the fc loop)
-    // Where a layer's BatchNorm-backward sums follow from the weight gradient (no dropout in between), ONE launch forms the sums and the
-    // coefficients + dgamma / dbeta (bn_bwd_from_wgrad_kernel, round 4); coef_ready then tells the next bwd_finalize site that `coef` is
-    // final.  Synchronised BatchNorm keeps the two-kernel form: the sums must cross the ranks as a row.
-    bool coef_ready = false;
-    auto from_wgrad = [&](const float* praw_, const float* W_, const float* db_, int F_, int K_, int mode_, int l) -> int {
-        const int C_ = kLayerC[l], nfold_ = K_ / C_;
-        hipLaunchKernelGGL(bn_bwd_from_wgrad_kernel, dim3(C_ / 16), dim3(256), 0, st, praw_, W_, db_, F_, K_, mode_, C_, nfold_, (double)N * nfold_,
-                           stats(l), coef, g->bn_g[l], g->bn_b[l]);
-        hipError_t e = hipGetLastError();
-        coef_ready = true;
-        return e == hipSuccess ? 0 : fail((int)e, "bn_bwd_from_wgrad_kernel");
-    };
     const bool fuse_ok = sizeof(T) == 2 && !opt(c, CP_OPT_UNFUSED_BN_BWD);
     // ---- projection ------------------------------------------------------------------
     {
@@ -1511,11 +1496,9 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         CKL("reduce_slabs(last)");
         if (!drop) {
             // BN-backward sums of fc7's BN from the projection's weight gradient (no N-sized read)
-            if (c->stats_allreduce) {
-                hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials,
-                                   CP_D_E, 512, 0);
-                CKL("bn_bwd_sums_from_wgrad_kernel(last)");
-            } else if (int e = from_wgrad(praw, p->last_w, dzsum, CP_D_E, 512, 0, 8)) return e;
+            hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials,
+                               CP_D_E, 512, 0);
+            CKL("bn_bwd_sums_from_wgrad_kernel(last)");
             stat_rows = 1;
         }
         GemmNTArgs a{};
@@ -1528,8 +1511,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // no dropout behind fc7: its BN-backward sums are known (from the projection's weight gradient), so this
             // launch applies fc7's BN + ReLU backward itself, as the fc launches below do for their layer below
             int nr = stat_rows;
-            if (!coef_ready) { if (int e = bwd_finalize(partials, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, fused)")) return e; }
-            coef_ready = false;
+            if (int e = bwd_finalize(partials, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, fused)")) return e;
             a.R = act(8); a.coef = coef; a.coef_mod = 512;
             CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows, dyn_tiles(c))));
             nr = drows;
@@ -1574,9 +1556,8 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         if (!bn_done) {
             ProfScope ps(CP_K_BN_BWD, st);
             int nr = stat_rows;
-            const float* pp = coef_ready ? nullptr : pre(nr, 2 * 512);
-            if (!coef_ready) { if (int e = bwd_finalize(pp, nr, (double)N, L, 512, 1, "bn_bwd_finalize_kernel")) return e; }
-            coef_ready = false;
+            const float* pp = pre(nr, 2 * 512);
+            if (int e = bwd_finalize(pp, nr, (double)N, L, 512, 1, "bn_bwd_finalize_kernel")) return e;
             const int gb = grid_rows(N, 256 / (512 / D::EPC), 2048);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
             nr = gb;
@@ -1637,11 +1618,9 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             if (!in_drop) {
                 // no dropout between this layer and the previous BN: its backward sums follow from P = g_y^T r
                 // (just reduced), W and db -- the data-gradient launch below then reads no saved activation
-                if (c->stats_allreduce) {
-                    hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(K / 64, kSumSlices), dim3(256), 0, st, praw, p->fc_w[i],
-                                       g->fc_b[i], partials, 512, K, i == 0 ? 1 : 0);
-                    CKL("bn_bwd_sums_from_wgrad_kernel");
-                } else if (int e = from_wgrad(praw, p->fc_w[i], g->fc_b[i], 512, K, i == 0 ? 1 : 0, Lp)) return e;
+                hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(K / 64, kSumSlices), dim3(256), 0, st, praw, p->fc_w[i],
+                                   g->fc_b[i], partials, 512, K, i == 0 ? 1 : 0);
+                CKL("bn_bwd_sums_from_wgrad_kernel");
             }
         }
         stat_rows = in_drop ? tiles_n : kSumSlices;
@@ -1655,13 +1634,12 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // layer Lp's BN-backward sums exist already (from the weight gradient above): finalise its coefficients
             // now and let this launch's epilogue apply BN backward + the ReLU mask to its own output tile
             const int Cp = kLayerC[Lp], nfold = K / Cp;                   // fc below: 512 x 1; conv2 below: 64 x 12
-            if (!coef_ready) {
+            {
                 ProfScope ps(CP_K_BN_BWD, st);
                 int nr = stat_rows;
                 const float* pp = pre(nr, 2 * K);
                 if (int e = bwd_finalize(pp, nr, (double)N * nfold, Lp, Cp, nfold, "bn_bwd_finalize_kernel(fused)")) return e;
             }
-            coef_ready = false;
             a.R = act(Lp); a.coef = coef; a.coef_mod = Cp;
             int drows = 0;
             {
@@ -1687,7 +1665,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         }
         T* tmp = cur; cur = nxt; nxt = tmp;
     }
-    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, cur, nxt, bn_done, stat_rows, coef_ready);
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, cur, nxt, bn_done, stat_rows);
 }
 
 
@@ -1754,13 +1732,6 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
     uint8_t* nxt = base + w.g8[1];
     int stat_rows = 0;
     bool bn_done = false;
-    auto from_wgrad = [&](const float* W_, const float* db_, int F_, int K_, int mode_, int l) -> int {      // (encoder_backward_t: sums + coefficients in one launch)
-        const int C_ = kLayerC[l], nfold_ = K_ / C_;
-        hipLaunchKernelGGL(bn_bwd_from_wgrad_kernel, dim3(C_ / 16), dim3(256), 0, st, praw, W_, db_, F_, K_, mode_, C_, nfold_, (double)N * nfold_,
-                           stats(l), coef, g->bn_g[l], g->bn_b[l]);
-        hipError_t e = hipGetLastError();
-        return e == hipSuccess ? 0 : fail((int)e, "bn_bwd_from_wgrad_kernel");
-    };
     // ---- projection ------------------------------------------------------------------
     {
         ProfScope ps(CP_K_PROJ_BWD, st);
@@ -1800,11 +1771,9 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             if (int e = bwd_finalize(pp, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
         } else {
             // no dropout behind fc7: its BatchNorm-backward sums follow from the projection's weight gradient (no N-sized read)
-            if (c->stats_allreduce) {
-                hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials, CP_D_E, 512, 0);
-                CKL("bn_bwd_sums_from_wgrad_kernel(last)");
-                if (int e = bwd_finalize(partials, 1, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, fused)")) return e;
-            } else if (int e = from_wgrad(p->last_w, dzsum, CP_D_E, 512, 0, 8)) return e;
+            hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials, CP_D_E, 512, 0);
+            CKL("bn_bwd_sums_from_wgrad_kernel(last)");
+            if (int e = bwd_finalize(partials, 1, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, fused)")) return e;
         }
         a.coef = coef;
         CK(launch_proj_dgrad8<1>(a, st, &drows));
@@ -1873,11 +1842,9 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
                                i == 0 ? 1 : 0, in_drop ? (float*)nullptr : praw, (const int*)&fs->e[tx], (const int*)&fs->e[ty]);
             CKL("reduce_slabs(fc)");
             if (!in_drop) {
-                if (c->stats_allreduce) {
-                    hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(K / 64, kSumSlices), dim3(256), 0, st, praw, p->fc_w[i], g->fc_b[i],
-                                       partials, 512, K, i == 0 ? 1 : 0);
-                    CKL("bn_bwd_sums_from_wgrad_kernel");
-                } else if (int e = from_wgrad(p->fc_w[i], g->fc_b[i], 512, K, i == 0 ? 1 : 0, Lp)) return e;
+                hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(K / 64, kSumSlices), dim3(256), 0, st, praw, p->fc_w[i], g->fc_b[i],
+                                   partials, 512, K, i == 0 ? 1 : 0);
+                CKL("bn_bwd_sums_from_wgrad_kernel");
             }
         }
         Wsd8Args a{};
@@ -1886,7 +1853,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         bn_done = false;
         if (!in_drop) {
             const int Cp = kLayerC[Lp], nfold = K / Cp;
-            if (c->stats_allreduce) {       // (else: the coefficients came with the sums)
+            {
                 ProfScope ps(CP_K_BN_BWD, st);
                 int nr = kSumSlices;
                 const float* pp = pre(nr, 2 * K);

@@ -526,48 +526,6 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
 }
 
 // ------------------------------------------------------------------------------------
-// The two kernels below in ONE launch (round 4; rank-local BatchNorm -- synchronised BatchNorm needs the sums as a row that can
-// cross the ranks and keeps the pair): for 16 channels per block, S1 / S2 over ALL F rows of W and P (16 row lanes x F/16 rows,
-// 64-byte row segments), then bn_bwd_finalize_kernel's arithmetic on the block's own channels.  nfold > 1 (fc1 -> conv2's
-// BatchNorm2d, mode 1): column kp = f*C + c of P belongs to channel c, and W is indexed in the reference order k = c*12 + f.
-// grid C/16 blocks of 256 threads.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_from_wgrad_kernel(const float* __restrict__ P, const float* __restrict__ W,
-                                                                const float* __restrict__ db, int F, int Kp, int mode, int C, int nfold,
-                                                                double count, const float* __restrict__ stats, float* __restrict__ coef,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double red[2][16][16];
-    const int tid = threadIdx.x, cl = tid & 15, g = tid >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    double s1 = 0, s2 = 0;
-    for (int f = 0; f < nfold; ++f) {
-        const int kp = f * C + c;
-        const int k = mode == 1 ? c * 12 + f : kp;
-#pragma unroll 4
-        for (int j = g; j < F; j += 16) {
-            const double w = (double)W[(int64_t)j * Kp + k];
-            s1 += w * (double)db[j];
-            s2 += w * (double)P[(int64_t)j * Kp + kp];
-        }
-    }
-    red[0][g][cl] = s1;
-    red[1][g][cl] = s2;
-    __syncthreads();
-    if (g == 0) {
-        s1 = s2 = 0;
-        for (int q = 0; q < 16; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
-        const double mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c];
-        const double dot = (s2 - mean * s1) * invstd;          // sum g * x_hat
-        const double c1 = s1 / count, c2 = dot / count;
-        coef[0 * C + c] = (float)sc;
-        coef[1 * C + c] = (float)(-sc * invstd * c2);
-        coef[2 * C + c] = (float)(-sc * (c1 - mean * invstd * c2));
-        dgamma[c] = (float)dot;
-        dbeta[c] = (float)s1;
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // BN-backward sums of the PREVIOUS layer without touching any N-sized tensor.  With g_v = g_y W
 // (no dropout in between) and P = g_y^T r the raw weight-gradient product of this layer:
 //     S1[k] = sum_n g_v[n][k]          = sum_j W[j][k] * db[j]          (db = column sums of g_y)
