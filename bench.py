@@ -73,7 +73,7 @@ def gemm_symbol(kind: str, dyn: str, dtype: str = "bf16") -> str:
     return GEMM_KERNELS[dtype][kind].format(dyn=dyn)
 
 
-def gemm_model(kind: str, n: int, dtype: str, dropout: bool):
+def gemm_model(kind: str, n: int, dtype: str, dropout: bool, paired_wgrads: int = 2):
     """Algorithmic (bytes, flops) of ONE average launch of a GEMM kind over n windows (DESIGN.md
     'measurement'): fc layers are 768->512 then 6 x 512->512; every activation/gradient element is
     moved once per kernel that must touch it (BN-barrier model), at the element size of the dtype
@@ -104,7 +104,7 @@ def gemm_model(kind: str, n: int, dtype: str, dropout: bool):
         return 0.0, 0.0
     launches = len(layers)
     if kind == "fc_wgrad" and dropout and dtype != "f32":
-        launches -= 2               # behind a dropout: fc7+fc6 and fc5+fc4 share one launch each (api.hip, defer_wgrad)
+        launches -= paired_wgrads   # behind a dropout: fc7+fc6 (and, on one stream, fc5+fc4) share one launch each (api.hip, defer_wgrad)
     byts = sum(n * es * per(ks[i]) for i in layers) / launches
     flops = sum(2.0 * n * 512 * ks[i] for i in layers) / launches
     return byts, flops
@@ -557,7 +557,8 @@ def main():
                 if kname in k:
                     traffic = dict(value=v["hbm_bytes_per_launch"], source="profiles/" + os.path.basename(tpath) + " (PMC FETCH_SIZE / WRITE_SIZE passes, builder's box)")
         avg_s = ms / launches / 1e3
-        byts, flops = gemm_model(dom, N, dt, args.dp_emg > 0)
+        paired = 1 if eng._aux is not None else 2
+        byts, flops = gemm_model(dom, N, dt, args.dp_emg > 0, paired)
         gbs = byts / avg_s / 1e9
         tfl = flops / avg_s / 1e12
         mfma_peak = MFMA_PEAK_TFLOPS[dt]
@@ -565,7 +566,7 @@ def main():
         per_kernel = {}
         for k in gemm_kinds:
             if k in prof and prof[k][1] > 0:
-                kb, kf = gemm_model(k, N, dt, args.dp_emg > 0)
+                kb, kf = gemm_model(k, N, dt, args.dp_emg > 0, paired)
                 ks_ = prof[k][0] / prof[k][1] / 1e3
                 per_kernel[k] = dict(symbol=gemm_symbol(k, dyn, dt), launches=prof[k][1], avg_us=ks_ * 1e6, algorithmic_bytes=kb,
                                      gbs=kb / ks_ / 1e9, hbm_frac=kb / ks_ / 1e9 / HBM_PEAK_GBS, tflops=kf / ks_ / 1e12)

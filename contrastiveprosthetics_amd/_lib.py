@@ -50,6 +50,7 @@ class cp_config(C.Structure):
         ("options", C.c_uint32), ("tile_schedule", C.c_int32),
         ("stats_allreduce", C.c_void_p), ("stats_user", C.c_void_p), ("stats_world", C.c_int32), ("reserved0", C.c_int32),
         ("grad_tap", C.c_void_p), ("grad_tap_bytes", C.c_size_t),
+        ("aux_stream", C.c_void_p), ("aux_fork", C.c_void_p), ("aux_join", C.c_void_p),
     ]
 
 

@@ -176,6 +176,9 @@ struct WS {
     size_t head_part;        // f32
     size_t sm_acc;                // i64 [18][2][768]: fixed-point BatchNorm totals of the small-batch form (csrc/small.cuh): forward layers 0..8, backward 9..17
     size_t sync_loc, sync_glob;   // f32 [2][768] each: one row of statistics, this rank's and the sum over ranks (sync BN)
+    // second stream (cp_config.aux_stream): gradients that a floating weight-gradient launch still reads must outlive the ping-pong --
+    // gkeep[q] = dL/d(pre-activation) of fc7, fc6, fc5 (T [N][512]; CP_FP8: e5m2 bytes); slabs_b = that stream's own slab region
+    size_t gkeep[3], slabs_b;
     // CP_FP8 (csrc/fp8.cuh): the scale table (ALWAYS at offset 0, so that it survives a change of n_windows), the e4m3 activations,
     // dropout outputs and fc weights with their scale bytes; the 16-bit buffers above are then what the bf16 backward kernels read
     size_t f8state, act8[CP_N_BN], u8[3], wfc8[CP_N_FC], wsc8[CP_N_FC];
@@ -232,6 +235,8 @@ static WS carve(int64_t N, int dtype, float dp) {
     w.sm_acc = take((size_t)18 * 2 * 768 * 8);
     w.sync_loc = take(2 * 768 * 4);
     w.sync_glob = take(2 * 768 * 4);
+    for (int i = 0; i < 3; ++i) w.gkeep[i] = dp > 0.f ? take((size_t)N * 512 * (dtype == CP_FP8 ? 1 : es)) : 0;
+    w.slabs_b = dp > 0.f ? take(kSlabFloats * 4) : 0;
     w.total = o;
     return w;
 }
@@ -771,8 +776,9 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
     return 0;
 }
 
+struct Aux;
 template <typename T> static int conv_backward_tail(const cp_config*, const cp_params*, const float*, unsigned char*, const WS&, cp_params*, hipStream_t,
-                                                    hipEvent_t, T*, T*, bool, int);
+                                                    hipEvent_t, T*, T*, bool, int, const Aux* aux = nullptr);
 
 template <typename T>
 static int encoder_backward_small_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
@@ -1321,15 +1327,47 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
     *splits = (int)((M + rps - 1) / rps);
 }
 
+// The second stream of cp_encoder_backward (cp_config.aux_stream; cpnative.h).  fork(): what is on `main` so far precedes what is
+// enqueued on `side` from now on; join(): what is on `side` so far precedes what is enqueued on `main` from now on.  One event each, re-recorded:
+// a stream's wait refers to the record that precedes it.
+struct Aux {
+    hipStream_t main, side;
+    hipEvent_t fork_ev, join_ev;
+    bool on;
+    int fork() const {
+        if (!on) return 0;
+        CK(hipEventRecord(fork_ev, main));
+        CK(hipStreamWaitEvent(side, fork_ev, 0));
+        return 0;
+    }
+    int join() const {
+        if (!on) return 0;
+        CK(hipEventRecord(join_ev, side));
+        CK(hipStreamWaitEvent(main, join_ev, 0));
+        return 0;
+    }
+    hipStream_t s() const { return on ? side : main; }
+};
+static Aux make_aux(const cp_config* c, hipStream_t st, bool eligible) {
+    Aux a{st, st, nullptr, nullptr, false};
+    if (eligible && c->aux_stream && c->aux_fork && c->aux_join && !c->stats_allreduce && !c->grad_tap) {
+        a.side = (hipStream_t)c->aux_stream; a.fork_ev = (hipEvent_t)c->aux_fork; a.join_ev = (hipEvent_t)c->aux_join;
+        a.on = a.side != st;
+    }
+    return a;
+}
+
 // conv stack of the backward pass (shared by the 16/32-bit and the 8-bit fc paths): cur = dL/d(BN2 output), or dL/d(conv2
 // pre-activation) when bn_done, as [N][768] == [(N*12)][64] T; nxt = scratch of the same size
 template <typename T>
 static int conv_backward_tail(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
-                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows) {
+                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows, const Aux* aux) {
     using D = DT<T>;
     const int64_t N = c->n_windows, R12 = N * 12;
     float* partials = (float*)(base + w.partials);
-    float* slabs = (float*)(base + w.slabs);
+    const bool side = aux && aux->on && bn_done;          // conv2's weight gradient on the second stream (its input `cur` is final on entry)
+    float* slabs = (float*)(base + (side ? w.slabs_b : w.slabs));
+    const hipStream_t sw = side ? aux->side : st;
     float* coef = (float*)(base + w.coef);
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
@@ -1349,7 +1387,11 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
     };
     // every gradient but the conv stack's is final here (cp_encoder_backward_ev): a data-parallel caller starts summing
     // them across ranks while the conv backward below still runs
-    if (fc_grads_ready) CK(hipEventRecord(fc_grads_ready, st));
+    if (fc_grads_ready) {
+        if (aux) { if (int e = aux->join()) return e; }          // (the fc weight gradients that ran on the second stream included)
+        CK(hipEventRecord(fc_grads_ready, st));
+    }
+    if (side) { if (int e = aux->fork()) return e; }
     // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
     {
         if (!bn_done) {
@@ -1368,23 +1410,23 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
         ConvArgs ca{};
         ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0); ca.gin = cur; ca.n_windows = N;
         {
-            ProfScope ps(CP_K_CONV2_WGRAD, st);
+            ProfScope ps(CP_K_CONV2_WGRAD, sw);
             const int64_t strips = (N + CONV_WG_WPB - 1) / CONV_WG_WPB;
             const int64_t cap = sizeof(T) == 2 ? 512 : 256;      // two blocks per CU (194 registers with the strip prefetch)
             const int S = (int)(strips < cap ? strips : cap);
             ca.partials = slabs;
-            hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
+            hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, sw, ca);
             // up to 512 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
             // unused tail of the slab buffer), then the scatter kernel walks 32 instead of 512
             const float* sl = slabs;
             int ns = S;
             if (S > 2 * REDUCE_SLICES) {
                 float* folded = slabs + (size_t)S * 64 * 192;
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(64 * 192 / 64, REDUCE_SLICES), dim3(256), 0, st, slabs, S, 64 * 192, folded);
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(64 * 192 / 64, REDUCE_SLICES), dim3(256), 0, sw, slabs, S, 64 * 192, folded);
                 sl = folded;
                 ns = REDUCE_SLICES;
             }
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, st, sl, ns, 64, 192, 64, (const float*)nullptr,
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, sw, sl, ns, 64, 192, 64, (const float*)nullptr,
                                (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2, (float*)nullptr);
             CKL("conv2_wgrad_kernel");
         }
@@ -1412,6 +1454,7 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
         hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, g->conv1_w, g->conv1_b);
         CKL("conv1_bwd_kernel");
     }
+    if (aux) { if (int e = aux->join()) return e; }      // everything the second stream was given is part of this call
     return 0;
 }
 
@@ -1460,6 +1503,14 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     T* nxt = (T*)(base + w.gbuf[1]);
     bool bn_done = false;           // (see the comment above the fc loop)
     const bool fuse_ok = sizeof(T) == 2 && !opt(c, CP_OPT_UNFUSED_BN_BWD);
+    // Second stream (cp_config.aux_stream, round 4): the weight gradients behind a dropout -- the projection's, fc7's + fc6's (one
+    // paired launch), fc5's -- and conv2's float there beside the critical path's ~40 small launches.  Their gradient operands then
+    // live in buffers of their own (w.gkeep) instead of the ping-pong, so that no data-gradient launch has to wait for them.
+    // (not for the CP_OPT_FP8_BRIDGE test route, which runs this function on a CP_FP8 workspace: its gkeep buffers hold bytes)
+    const Aux aux = make_aux(c, st, fuse_ok && drop && !dyn_tiles(c) && !opt(c, CP_OPT_UNPAIRED_WGRAD) && c->dtype != CP_FP8);
+    float* slabs_b = (float*)(base + w.slabs_b);
+    if (aux.on) { cur = (T*)(base + w.gkeep[0]); nxt = (T*)(base + w.gkeep[1]); }
+    if (int e = aux.fork()) return e;           // dz (cp_head) is final
     // ---- projection ------------------------------------------------------------------
     {
         ProfScope ps(CP_K_PROJ_BWD, st);
@@ -1474,7 +1525,8 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             CKL("colsum(dz)");
         }
         GemmTNArgs ta{};
-        ta.X = dz; ta.ldx = 64; ta.Y = Y; ta.ldy = 512; ta.slabs = slabs; ta.M = N; ta.P = 64; ta.Q = 512;
+        const hipStream_t sw = aux.s();                 // (with dropout nothing waits for this weight gradient: second stream)
+        ta.X = dz; ta.ldx = 64; ta.Y = Y; ta.ldy = 512; ta.slabs = aux.on ? slabs_b : slabs; ta.M = N; ta.P = 64; ta.Q = 512;
         int S;
         split_rows(N, 128, &S, &ta.rows_per_split);
 #ifdef CP_VARIANTS
@@ -1486,12 +1538,12 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // u8 = dropout(BN(fc7)) was never written (encoder_forward_t): formed from the saved activation while staging
             ta.Y = act(8); ta.y_scale = stats(8) + 2 * 512; ta.y_shift = stats(8) + 3 * 512;
             ta.dp_thresh = dp_thresh(c->dp_emg); ta.dp_key = dp_key(c, 8); ta.dp_inv_keep = dp_inv_keep(c->dp_emg); ta.dp_salt = dp_salt(c);
-            CK((launch_gemm_tn<T, 64, 128, YLOAD_BNDROP>(ta, S, st)));
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_BNDROP>(ta, S, sw)));
         } else {
-            CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, sw)));
         }
         float* praw = (float*)(base + w.praw);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
                            drop ? (float*)nullptr : praw);
         CKL("reduce_slabs(last)");
         if (!drop) {
@@ -1578,23 +1630,29 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         // next layer's (the gradient buffer they read is the ping-pong partner, untouched until that layer's data
         // gradient): two problems x 4 tiles x 32 splits fill the GPU with half the f32 slabs per layer (134 -> 67 MB
         // written and re-read).
-        const bool defer_wgrad = sizeof(T) == 2 && in_drop && (i == 6 || i == 4) && fcK(i - 1) == 512 && !opt(c, CP_OPT_UNPAIRED_WGRAD);
+        // (second stream: fc7 waits for fc6 as before -- one paired launch -- but fc5 goes alone: fc4's weight gradient is on the critical
+        //  path, its product carries the BatchNorm-backward sums of the layer below)
+        const bool defer_wgrad = sizeof(T) == 2 && in_drop && (i == 6 || (i == 4 && !aux.on)) && fcK(i - 1) == 512 && !opt(c, CP_OPT_UNPAIRED_WGRAD);
+        const bool floats = aux.on && in_drop;           // this layer's weight gradient and slab reduction run on the second stream
+        const hipStream_t sw = floats ? aux.side : st;
+        float* wslabs = floats ? slabs_b : slabs;
+        if (floats && !defer_wgrad) { if (int e = aux.fork()) return e; }      // cur (and the deferred layer's gradient, and both bias gradients) are final
         if (defer_wgrad) {
             pend.X = cur; pend.Y = Y; pend.i = i;
             pending = true;
         } else if constexpr (sizeof(T) == 2) {
             // 256x256 tiles: 4 (K=512) or 6 (K=768) tiles x ~256/tiles splits = one block per CU
             GemmTN256Args ta{};
-            ta.X = (const bf16_t*)cur; ta.ldx = 512; ta.Y = (const bf16_t*)Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
+            ta.X = (const bf16_t*)cur; ta.ldx = 512; ta.Y = (const bf16_t*)Y; ta.ldy = K; ta.slabs = wslabs; ta.M = N; ta.P = 512; ta.Q = K;
             if (pending) {
-                ta.X2 = (const bf16_t*)pend.X; ta.Y2 = (const bf16_t*)pend.Y; ta.slabs2 = slabs + (size_t)32 * 512 * 512;
+                ta.X2 = (const bf16_t*)pend.X; ta.Y2 = (const bf16_t*)pend.Y; ta.slabs2 = wslabs + (size_t)32 * 512 * 512;
                 split_rows(N, 32, &S, &ta.rows_per_split);
             } else {
                 split_rows(N, K == 512 ? 64 : 40, &S, &ta.rows_per_split);
             }
             ta.splits = S;
-            ProfScope ps(CP_K_FC_WGRAD, st);
-            CK(launch_gemm_tn256(ta, st));
+            ProfScope ps(CP_K_FC_WGRAD, sw);
+            CK(launch_gemm_tn256(ta, sw));
         } else {
             GemmTNArgs ta{};
             ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
@@ -1603,16 +1661,16 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             CK((launch_gemm_tn<T, 128, 128, YLOAD_PLAIN>(ta, S, st)));
         }
         if (!defer_wgrad) {
-            ProfScope ps(CP_K_REDUCE_SLABS, st);
+            ProfScope ps(CP_K_REDUCE_SLABS, sw);
             float* praw = (float*)(base + w.praw);
             if (pending) {
                 // the deferred layer (always behind a dropout: no BN fold to undo, no raw product wanted)
-                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
+                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, sw, wslabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
                                    (const float*)nullptr, (const float*)nullptr, g->fc_b[pend.i], g->fc_w[pend.i], 0, (float*)nullptr);
                 CKL("reduce_slabs(fc, deferred)");
                 pending = false;
             }
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, sw, wslabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
                                i == 0 ? 1 : 0, in_drop ? (float*)nullptr : praw);
             CKL("reduce_slabs(fc)");
             if (!in_drop) {
@@ -1663,9 +1721,15 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows, dyn_tiles(c))));
             if (in_drop) stat_rows = drows;
         }
-        T* tmp = cur; cur = nxt; nxt = tmp;
+        if (aux.on && L >= 6) {
+            // the gradients the floating launches read (layers 8, 7, 6) stay where they are; from layer 5 on the usual ping-pong
+            cur = nxt;
+            nxt = L == 8 ? (T*)(base + w.gkeep[2]) : (T*)(base + w.gbuf[L == 7 ? 0 : 1]);
+        } else {
+            T* tmp = cur; cur = nxt; nxt = tmp;
+        }
     }
-    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, cur, nxt, bn_done, stat_rows);
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, cur, nxt, bn_done, stat_rows, &aux);
 }
 
 
@@ -1732,6 +1796,11 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
     uint8_t* nxt = base + w.g8[1];
     int stat_rows = 0;
     bool bn_done = false;
+    // second stream (encoder_backward_t): the projection's, fc7's + fc6's, fc5's and conv2's weight gradients float beside the critical path
+    const Aux aux = make_aux(c, st, drop);
+    float* slabs_b = (float*)(base + w.slabs_b);
+    if (aux.on) { cur = base + w.gkeep[0]; nxt = base + w.gkeep[1]; }
+    if (int e = aux.fork()) return e;
     // ---- projection ------------------------------------------------------------------
     {
         ProfScope ps(CP_K_PROJ_BWD, st);
@@ -1745,18 +1814,19 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             CKL("colsum(dz)");
         }
         GemmTNArgs ta{};
-        ta.X = dz; ta.ldx = 64; ta.Y = base + w.act8[8]; ta.ldy = 512; ta.slabs = slabs; ta.M = N; ta.P = 64; ta.Q = 512;
+        const hipStream_t sw = aux.s();
+        ta.X = dz; ta.ldx = 64; ta.Y = base + w.act8[8]; ta.ldy = 512; ta.slabs = aux.on ? slabs_b : slabs; ta.M = N; ta.P = 64; ta.Q = 512;
         ta.y_exp = &fs->e[F8_T_ACT + 8];
         int S;
         split_rows(N, 128, &S, &ta.rows_per_split);
         if (drop) {
             ta.y_scale = stats(8) + 2 * 512; ta.y_shift = stats(8) + 3 * 512;
             ta.dp_thresh = dp_thresh(c->dp_emg); ta.dp_key = dp_key(c, 8); ta.dp_inv_keep = dp_inv_keep(c->dp_emg); ta.dp_salt = dp_salt(c);
-            CK((launch_gemm_tn<T, 64, 128, YLOAD_BNDROP_F8>(ta, S, st)));
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_BNDROP_F8>(ta, S, sw)));
         } else {
-            CK((launch_gemm_tn<T, 64, 128, YLOAD_F8>(ta, S, st)));
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_F8>(ta, S, sw)));
         }
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
                            drop ? (float*)nullptr : praw, (const int*)nullptr, (const int*)nullptr);
         CKL("reduce_slabs(last)");
         Proj8Args a{};
@@ -1810,13 +1880,17 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         const float* s = in_drop ? nullptr : stats(Lp) + 2 * kLayerC[Lp];
         const float* t = in_drop ? nullptr : stats(Lp) + 3 * kLayerC[Lp];
         int S;
-        const bool defer_wgrad = in_drop && (i == 6 || i == 4) && fcK(i - 1) == 512;
+        const bool defer_wgrad = in_drop && (i == 6 || (i == 4 && !aux.on)) && fcK(i - 1) == 512;
+        const bool floats = aux.on && in_drop;
+        const hipStream_t sw = floats ? aux.side : st;
+        float* wslabs = floats ? slabs_b : slabs;
+        if (floats && !defer_wgrad) { if (int e = aux.fork()) return e; }
         if (defer_wgrad) {
             pend.X = cur; pend.Y = Y; pend.i = i; pend.tx = tx; pend.ty = ty;
             pending = true;
         } else {
             GemmTN8Args ta{};
-            ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = slabs; ta.M = N; ta.P = 512; ta.Q = K;
+            ta.X = cur; ta.ldx = 512; ta.Y = Y; ta.ldy = K; ta.slabs = wslabs; ta.M = N; ta.P = 512; ta.Q = K;
             // (32 splits for the single-layer launches too -- half the slab bytes, half the blocks -- measured: weight gradients 5 x 67 -> 82 us,
             //  slab reductions 9 x 11.0 -> 9.1: 70 us lost for 17 gained)
             const int target = pending ? 32 : (K == 512 ? 64 : 40);
@@ -1824,21 +1898,21 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             rps = ((rps + 63) / 64) * 64;
             ta.rows_per_split = rps;
             S = (int)((N + rps - 1) / rps);
-            if (pending) { ta.X2 = pend.X; ta.Y2 = pend.Y; ta.slabs2 = slabs + (size_t)32 * 512 * 512; }
+            if (pending) { ta.X2 = pend.X; ta.Y2 = pend.Y; ta.slabs2 = wslabs + (size_t)32 * 512 * 512; }
             ta.splits = S;
-            ProfScope ps(CP_K_FC_WGRAD, st);
-            CK(launch_gemm_tn8(ta, st));
+            ProfScope ps(CP_K_FC_WGRAD, sw);
+            CK(launch_gemm_tn8(ta, sw));
         }
         if (!defer_wgrad) {
-            ProfScope ps(CP_K_REDUCE_SLABS, st);
+            ProfScope ps(CP_K_REDUCE_SLABS, sw);
             if (pending) {
-                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
+                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, sw, wslabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
                                    (const float*)nullptr, (const float*)nullptr, g->fc_b[pend.i], g->fc_w[pend.i], 0, (float*)nullptr,
                                    (const int*)&fs->e[pend.tx], (const int*)&fs->e[pend.ty]);
                 CKL("reduce_slabs(fc, deferred)");
                 pending = false;
             }
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, st, slabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, sw, wslabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
                                i == 0 ? 1 : 0, in_drop ? (float*)nullptr : praw, (const int*)&fs->e[tx], (const int*)&fs->e[ty]);
             CKL("reduce_slabs(fc)");
             if (!in_drop) {
@@ -1884,9 +1958,14 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             CK((launch_gemm_wsd8<1, false>(a, st, &drows)));
             stat_rows = drows;
         }
-        uint8_t* tmp = cur; cur = nxt; nxt = tmp;
+        if (aux.on && L >= 6) {
+            cur = nxt;
+            nxt = L == 8 ? base + w.gkeep[2] : base + w.g8[L == 7 ? 0 : 1];
+        } else {
+            uint8_t* tmp = cur; cur = nxt; nxt = tmp;
+        }
     }
-    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gconv, (T*)(base + w.gbuf[1]), true, 0);
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gconv, (T*)(base + w.gbuf[1]), true, 0, &aux);
 }
 
 extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,

@@ -232,6 +232,11 @@ class Engine:
         self._sync_cb = None
         self._sync_world = 1
         self._fp8_seen_forward = False
+        # second stream for the weight gradients that nothing in the step waits for (cp_config.aux_stream; include/cpnative.h): created on
+        # first use; None/False = one stream.  $CPNATIVE_AUX_STREAM=0 switches it off for A/B runs.
+        import os as _os
+        self.aux_stream_enabled = _os.environ.get("CPNATIVE_AUX_STREAM", "1") != "0"
+        self._aux = None
         self.grad_tap: Optional[torch.Tensor] = None          # test aid (cp_config.grad_tap)
         self._ws: Optional[torch.Tensor] = None
         self._ws_windows = 0
@@ -275,6 +280,15 @@ class Engine:
         if self.grad_tap is not None:
             c.grad_tap = self.grad_tap.data_ptr()
             c.grad_tap_bytes = self.grad_tap.numel() * self.grad_tap.element_size()
+        if self.aux_stream_enabled and training and self._graph_state is None and self.dp_emg > 0.0 and self.dtype != CP_F32:
+            if self._aux is None:
+                with torch.cuda.device(self.device):
+                    self._aux = (torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event())
+                    for ev in self._aux[1:]:
+                        ev.record()                          # (torch creates the hipEvent_t lazily, at the first record)
+            c.aux_stream = self._aux[0].cuda_stream
+            c.aux_fork = self._aux[1].cuda_event
+            c.aux_join = self._aux[2].cuda_event
         return c
 
     def workspace(self, n_windows: int) -> torch.Tensor:

@@ -121,6 +121,20 @@ typedef struct cp_config {
      * n_windows x [12 positions][64 channels].  grad_tap_bytes = size of the buffer. */
     void* grad_tap;
     size_t grad_tap_bytes;
+    /* ---- a second stream for the work of cp_encoder_backward that nothing in the step waits for (round 4; all three NULL = one
+     * stream).  The weight gradients of the layers behind a dropout (fc5..fc7, the projection) and conv2's are not on the step's
+     * critical path -- their BatchNorm-backward sums come from the data-gradient launches -- while ~40 latency-bound finaliser /
+     * fold / reduction launches of the critical path leave most of the chip idle.  With aux_stream (a hipStream_t, ideally of
+     * LOWER priority than `stream`) those weight-gradient launches and their slab reductions are enqueued there: aux_fork (a
+     * hipEvent_t owned by the caller) is recorded on `stream` and waited for on aux_stream wherever a launch's inputs become
+     * final, aux_join is recorded on aux_stream and waited for on `stream` before the call returns (and before fc_grads_ready is
+     * recorded), so the caller sees the same stream-ordered semantics as without it.  Same kernels; fc5's and fc4's weight gradients are then summed over
+     * 64 row splits each instead of 32 (alone instead of in one paired launch): equal to the rounding of an f32 sum, run-to-run exact.
+     * Used by the large-batch 16- and 8-bit paths when dp_emg > 0; ignored elsewhere (f32, small batches, synchronised BatchNorm,
+     * a gradient tap). */
+    void* aux_stream;
+    void* aux_fork;
+    void* aux_join;
 } cp_config;
 
 /* Per-step values kept in DEVICE memory so that a whole training step can be captured in a HIP graph and replayed

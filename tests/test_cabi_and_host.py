@@ -49,7 +49,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.cp_params) == 8 * (4 + 7 + 7 + 9 + 9 + 3)
     assert ctypes.sizeof(_lib.cp_bn_buffers) == 8 * 18
     # 56 bytes of round 1-3 fields + options, tile_schedule, the sync-BN hook (fn, user, world, pad) and the gradient tap (ptr, bytes)
-    assert ctypes.sizeof(_lib.cp_config) == (8 + 4 * 4 + 4 * 4 + 8 + 8) + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8
+    assert ctypes.sizeof(_lib.cp_config) == (8 + 4 * 4 + 4 * 4 + 8 + 8) + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 3 * 8
     hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     body = hdr[hdr.index("typedef struct cp_config {"):hdr.index("} cp_config;")]
     fields = re.findall(r"\b(\w+)\s*;", body)
