@@ -285,6 +285,60 @@ static int check_cfg(const cp_config* c, void* ws, size_t ws_bytes, WS* out) {
     return 0;
 }
 
+// The second stream of cp_encoder_backward (cp_config.aux_stream; cpnative.h).  fork(): what is on `main` so far precedes what is
+// enqueued on `side` from now on; join(): what is on `side` so far precedes what is enqueued on `main` from now on.  One event each, re-recorded:
+// a stream's wait refers to the record that precedes it.
+struct Aux {
+    hipStream_t main, side;
+    hipEvent_t fork_ev, join_ev;
+    bool on;
+    int fork() const {
+        if (!on) return 0;
+        CK(hipEventRecord(fork_ev, main));
+        CK(hipStreamWaitEvent(side, fork_ev, 0));
+        return 0;
+    }
+    int join() const {
+        if (!on) return 0;
+        CK(hipEventRecord(join_ev, side));
+        CK(hipStreamWaitEvent(main, join_ev, 0));
+        return 0;
+    }
+    hipStream_t s() const { return on ? side : main; }
+};
+static Aux make_aux(const cp_config* c, hipStream_t st, bool eligible) {
+    Aux a{st, st, nullptr, nullptr, false};
+    if (eligible && c->aux_stream && c->aux_fork && c->aux_join && !c->stats_allreduce && !c->grad_tap) {
+        a.side = (hipStream_t)c->aux_stream; a.fork_ev = (hipEvent_t)c->aux_fork; a.join_ev = (hipEvent_t)c->aux_join;
+        a.on = a.side != st;
+    }
+    return a;
+}
+
+// the transposed weights the data-gradient launches read: fc1..fc7 and the projection (bf16 / f32), their e4m3 form + the projection's
+// (CP_FP8).  Made once per step: at the start of the backward pass, or -- second stream -- beside the forward pass.
+template <typename T>
+static int launch_weight_transposes(const cp_params* p, unsigned char* base, const WS& w, hipStream_t st) {
+    ProfScope ps(CP_K_PREP, st);
+    TransposeBatch tb{};
+    for (int i = 0; i < CP_N_FC; ++i) tb.job[i] = TransposeJob{p->fc_w[i], base + w.wfc_t[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
+    tb.job[CP_N_FC] = TransposeJob{p->last_w, base + w.wlast_t, CP_D_E, 512, 64, 0};
+    hipLaunchKernelGGL((transpose_w_batch_kernel<T>), dim3(128, CP_N_FC + 1), dim3(256), 0, st, tb);
+    CKL("transpose_w_batch_kernel");
+    return 0;
+}
+static int launch_weight_transposes_fp8(const cp_params* p, unsigned char* base, const WS& w, hipStream_t st) {
+    ProfScope ps(CP_K_PREP, st);
+    const Fp8State* fs = (const Fp8State*)(base + w.f8state);
+    Transpose8Batch tb{};
+    for (int i = 0; i < CP_N_FC; ++i)
+        tb.job[i] = Transpose8Job{p->fc_w[i], base + w.wfc8t[i], base + w.wsc8t[i], fcK(i), i == 0 ? 1 : 0, F8_T_GRAD + (i + 2)};
+    hipLaunchKernelGGL(transpose_w8_batch_kernel, dim3(12, CP_N_FC, 4), dim3(256), 0, st, tb, fs);
+    hipLaunchKernelGGL((transpose_w_kernel<bf16_t>), dim3(64), dim3(256), 0, st, p->last_w, (bf16_t*)(base + w.wlast_t), CP_D_E, 512, 64, 0);
+    CKL("transpose kernels (fp8)");
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // gather
 // ---------------------------------------------------------------------------------------
@@ -776,7 +830,6 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
     return 0;
 }
 
-struct Aux;
 template <typename T> static int conv_backward_tail(const cp_config*, const cp_params*, const float*, unsigned char*, const WS&, cp_params*, hipStream_t,
                                                     hipEvent_t, T*, T*, bool, int, const Aux* aux = nullptr);
 
@@ -859,18 +912,18 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
 // backward over this forward (a repeat finds the small-batch form's fixed-point totals already summed and zeroes them first).  A
 // consistency check only -- nothing an engine computes depends on another engine's entries.
 enum { PATH_LARGE = 0, PATH_SMALL = 1, PATH_FP8 = 2 };
-struct FwdNote { const void* ws; int64_t n; int path; int backwards; uint64_t tick; };
+struct FwdNote { const void* ws; int64_t n; int path; int backwards; uint64_t tick; int tposed; };
 static FwdNote g_notes[64];
 static uint64_t g_note_tick = 0;
 static std::mutex g_notes_mu;
-static void note_forward(const void* ws, int64_t n, int path) {
+static void note_forward(const void* ws, int64_t n, int path, int tposed = 0) {
     std::lock_guard<std::mutex> lk(g_notes_mu);
     FwdNote* slot = &g_notes[0];
     for (FwdNote& f : g_notes) {
         if (f.ws == ws) { slot = &f; break; }
         if (f.tick < slot->tick) slot = &f;
     }
-    *slot = FwdNote{ws, n, path, 0, ++g_note_tick};
+    *slot = FwdNote{ws, n, path, 0, ++g_note_tick, tposed};
 }
 // returns the number of backward passes already run over this forward, or -1 when the configurations disagree (-2: no forward on record)
 static int note_backward(const void* ws, int64_t n, int path) {
@@ -881,6 +934,12 @@ static int note_backward(const void* ws, int64_t n, int path) {
             return f.backwards++;
         }
     return -2;
+}
+static bool forward_made_transposes(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_notes_mu);
+    for (const FwdNote& f : g_notes)
+        if (f.ws == ws && f.tick) return f.tposed != 0;
+    return false;
 }
 static int last_forward_path(const void* ws) {
     std::lock_guard<std::mutex> lk(g_notes_mu);
@@ -896,8 +955,27 @@ extern "C" int cp_encoder_forward(const cp_config* cfg, const cp_params* p, cons
     if (int e = check_cfg(cfg, ws, ws_bytes, &w)) return e;
     if (!p || !x || !z_out) return fail(CP_ERR_ARG, "cp_encoder_forward args");
     if (((uintptr_t)x & 15) != 0) return fail(CP_ERR_ARG, "x must be 16-byte aligned");
-    note_forward(ws, cfg->n_windows, forward_path(cfg));
-    if (cfg->dtype == CP_FP8) return encoder_forward_fp8(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
+    // second stream (cp_config.aux_stream): the transposed weights of the backward pass are made beside the forward pass -- bf16 from its
+    // start, CP_FP8 behind it (their scale bytes need this step's gradient exponents, set by the forward's first launch)
+    const int path = forward_path(cfg);
+    const bool drop = cfg->training && cfg->dp_emg > 0.f;
+    const Aux aux = make_aux(cfg, (hipStream_t)stream, drop && path != PATH_SMALL && cfg->dtype != CP_F32 && !dyn_tiles(cfg) &&
+                                                           !opt(cfg, CP_OPT_UNPAIRED_WGRAD) && !opt(cfg, CP_OPT_UNFUSED_BN_BWD) && !opt(cfg, CP_OPT_FP8_BRIDGE));
+    note_forward(ws, cfg->n_windows, path, aux.on ? 1 : 0);
+    if (cfg->dtype == CP_FP8) {
+        if (int e = encoder_forward_fp8(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream)) return e;
+        if (aux.on) {
+            if (int e = aux.fork()) return e;
+            if (int e = launch_weight_transposes_fp8(p, (unsigned char*)ws, w, aux.side)) return e;
+            CK(hipEventRecord(aux.join_ev, aux.side));          // (waited for by cp_encoder_backward)
+        }
+        return 0;
+    }
+    if (aux.on) {
+        if (int e = aux.fork()) return e;
+        if (int e = launch_weight_transposes<bf16_t>(p, (unsigned char*)ws, w, aux.side)) return e;
+        CK(hipEventRecord(aux.join_ev, aux.side));
+    }
     if (use_small(cfg)) {
         if (cfg->dtype == CP_BF16) return encoder_forward_small_t<bf16_t>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
         return encoder_forward_small_t<float>(cfg, p, bn, x, (unsigned char*)ws, w, z_out, (hipStream_t)stream);
@@ -1327,36 +1405,6 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
     *splits = (int)((M + rps - 1) / rps);
 }
 
-// The second stream of cp_encoder_backward (cp_config.aux_stream; cpnative.h).  fork(): what is on `main` so far precedes what is
-// enqueued on `side` from now on; join(): what is on `side` so far precedes what is enqueued on `main` from now on.  One event each, re-recorded:
-// a stream's wait refers to the record that precedes it.
-struct Aux {
-    hipStream_t main, side;
-    hipEvent_t fork_ev, join_ev;
-    bool on;
-    int fork() const {
-        if (!on) return 0;
-        CK(hipEventRecord(fork_ev, main));
-        CK(hipStreamWaitEvent(side, fork_ev, 0));
-        return 0;
-    }
-    int join() const {
-        if (!on) return 0;
-        CK(hipEventRecord(join_ev, side));
-        CK(hipStreamWaitEvent(main, join_ev, 0));
-        return 0;
-    }
-    hipStream_t s() const { return on ? side : main; }
-};
-static Aux make_aux(const cp_config* c, hipStream_t st, bool eligible) {
-    Aux a{st, st, nullptr, nullptr, false};
-    if (eligible && c->aux_stream && c->aux_fork && c->aux_join && !c->stats_allreduce && !c->grad_tap) {
-        a.side = (hipStream_t)c->aux_stream; a.fork_ev = (hipEvent_t)c->aux_fork; a.join_ev = (hipEvent_t)c->aux_join;
-        a.on = a.side != st;
-    }
-    return a;
-}
-
 // conv stack of the backward pass (shared by the 16/32-bit and the 8-bit fc paths): cur = dL/d(BN2 output), or dL/d(conv2
 // pre-activation) when bn_done, as [N][768] == [(N*12)][64] T; nxt = scratch of the same size
 template <typename T>
@@ -1460,7 +1508,7 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
 
 template <typename T>
 static int encoder_backward_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
-                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready) {
+                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, bool tposed = false) {
     using D = DT<T>;
     const int64_t N = c->n_windows, R12 = N * 12;
     const bool drop = c->training && c->dp_emg > 0.f;
@@ -1489,14 +1537,6 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         return e == hipSuccess ? 0 : fail((int)e, what);
     };
 
-    {
-        ProfScope ps(CP_K_PREP, st);
-        TransposeBatch tb{};
-        for (int i = 0; i < CP_N_FC; ++i) tb.job[i] = TransposeJob{p->fc_w[i], base + w.wfc_t[i], 512, fcK(i), 512, i == 0 ? 1 : 0};
-        tb.job[CP_N_FC] = TransposeJob{p->last_w, base + w.wlast_t, CP_D_E, 512, 64, 0};
-        hipLaunchKernelGGL((transpose_w_batch_kernel<T>), dim3(128, CP_N_FC + 1), dim3(256), 0, st, tb);
-        CKL("transpose_w_batch_kernel");
-    }
 
     T* dz = (T*)(base + w.dz);
     T* cur = (T*)(base + w.gbuf[0]);
@@ -1510,6 +1550,8 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     const Aux aux = make_aux(c, st, fuse_ok && drop && !dyn_tiles(c) && !opt(c, CP_OPT_UNPAIRED_WGRAD) && c->dtype != CP_FP8);
     float* slabs_b = (float*)(base + w.slabs_b);
     if (aux.on) { cur = (T*)(base + w.gkeep[0]); nxt = (T*)(base + w.gkeep[1]); }
+    if (aux.on && tposed) CK(hipStreamWaitEvent(st, aux.join_ev, 0));      // the transposes made beside the forward pass (cp_encoder_forward)
+    else if (int e = launch_weight_transposes<T>(p, base, w, st)) return e;
     if (int e = aux.fork()) return e;           // dz (cp_head) is final
     // ---- projection ------------------------------------------------------------------
     {
@@ -1751,7 +1793,7 @@ __global__ __launch_bounds__(256) void dequant5_bf16_kernel(const uint8_t* __res
 // tensors to bf16, run the bf16 backward) for A/B runs and for the test that compares the two.
 // ---------------------------------------------------------------------------------------
 static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
-                                cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready) {
+                                cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, bool tposed = false) {
     using T = bf16_t;
     const int64_t N = c->n_windows;
     const bool drop = c->training && c->dp_emg > 0.f;
@@ -1782,15 +1824,6 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         CKL("dequant5_bf16_kernel");
         return 0;
     };
-    {
-        ProfScope ps(CP_K_PREP, st);
-        Transpose8Batch tb{};
-        for (int i = 0; i < CP_N_FC; ++i)
-            tb.job[i] = Transpose8Job{p->fc_w[i], base + w.wfc8t[i], base + w.wsc8t[i], fcK(i), i == 0 ? 1 : 0, F8_T_GRAD + (i + 2)};
-        hipLaunchKernelGGL(transpose_w8_batch_kernel, dim3(12, CP_N_FC, 4), dim3(256), 0, st, tb, (const Fp8State*)fs);
-        hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(64), dim3(256), 0, st, p->last_w, (T*)(base + w.wlast_t), CP_D_E, 512, 64, 0);
-        CKL("transpose kernels (fp8)");
-    }
     T* dz = (T*)(base + w.dz);
     uint8_t* cur = base + w.g8[0];
     uint8_t* nxt = base + w.g8[1];
@@ -1800,6 +1833,8 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
     const Aux aux = make_aux(c, st, drop);
     float* slabs_b = (float*)(base + w.slabs_b);
     if (aux.on) { cur = base + w.gkeep[0]; nxt = base + w.gkeep[1]; }
+    if (aux.on && tposed) CK(hipStreamWaitEvent(st, aux.join_ev, 0));
+    else if (int e = launch_weight_transposes_fp8(p, base, w, st)) return e;
     if (int e = aux.fork()) return e;
     // ---- projection ------------------------------------------------------------------
     {
@@ -1989,8 +2024,9 @@ extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, 
             return encoder_backward_small_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
         return encoder_backward_small_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
     }
+    const bool tposed = forward_made_transposes(ws);
     if (cfg->dtype == CP_FP8 && !opt(cfg, CP_OPT_FP8_BRIDGE))
-        return encoder_backward_fp8(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
+        return encoder_backward_fp8(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready, tposed);
     if (cfg->dtype == CP_FP8) {
         // (bridge = the first build's route, kept for A/B runs and as the test's comparison: the e4m3 tensors of the forward pass are
         //  expanded to bf16 -- exactly -- and the bf16 backward kernels run on them)
@@ -2010,7 +2046,7 @@ extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, 
         return encoder_backward_t<bf16_t>(cfg, p, x, base, w, grads, st, (hipEvent_t)fc_grads_ready);
     }
     if (cfg->dtype == CP_BF16)
-        return encoder_backward_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
+        return encoder_backward_t<bf16_t>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready, tposed);
     return encoder_backward_t<float>(cfg, p, x, (unsigned char*)ws, w, grads, (hipStream_t)stream, (hipEvent_t)fc_grads_ready);
 }
 
