@@ -44,7 +44,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}
 GEMM_KERNELS = {
     "bf16": {
         "fc_fwd_ws": "gemm_ws16_kernel",                      # weight-stationary forward, fc2..fc7 (K = 512), static schedule
-        "fc_fwd": "gemm_ws16k_kernel",                        # weight-stationary with the k range split over wave pairs: fc1 (K = 768)
+        "fc_fwd": "gemm_ws16n_kernel",                        # weight-stationary, 32 features x all 768 k per wave: fc1 (K = 768)
         "fc_dgrad": "gemm_nt256p_kernel<1, 4, {dyn}>",        # persistent, plain data gradient (only under CP_OPT_UNFUSED_BN_BWD)
         "fc_dgrad_bn": "gemm_wsd16_kernel<0>",                # + BN/ReLU backward of the layer below against the saved activation
         "fc_dgrad_stats": "gemm_wsd16_kernel<1>",             # behind a dropout: mask + BN-backward sums against the saved activation

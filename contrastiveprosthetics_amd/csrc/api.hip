@@ -397,9 +397,12 @@ static inline hipError_t launch_fc_gemm(const GemmNTArgs& a, hipStream_t st, int
         const bool ws_ok = !dyn, wsk_ok = !dyn, wsd_ok = !dyn;
 #endif
         // a process that has the GPU to itself (static schedule): the weight-stationary kernels (gemm_ws.cuh) -- K = 512 forward,
-        // fc1 (K = 768) on the split-k form, data gradients with BatchNorm + ReLU backward or (behind a dropout) the mask + sums
+        // fc1 (K = 768) on its narrow form (32 features per wave), data gradients with BatchNorm + ReLU backward or (behind a dropout) the mask + sums
         if (EPI == EPI_FWD && a.K == WS_K && a.lda == WS_K && a.relu && ws_ok) return launch_gemm_ws<EPI_FWD>(a, st, stat_rows);
-        if (EPI == EPI_FWD && a.K == WSK_K && a.lda == WSK_K && a.F == 512 && a.relu && wsk_ok) return launch_gemm_ws16k(a, st, stat_rows);
+#ifdef CP_VARIANTS
+        if (EPI == EPI_FWD && a.K == WSK_K && a.lda == WSK_K && a.F == 512 && a.relu && wsk_ok && (a.dbg & 1024)) return launch_gemm_ws16k(a, st, stat_rows);
+#endif
+        if (EPI == EPI_FWD && a.K == WSK_K && a.lda == WSK_K && a.F == 512 && a.relu && wsk_ok) return launch_gemm_ws16n(a, st, stat_rows);
 #ifdef CP_VARIANTS
         if ((EPI == EPI_FWD || (a.R == nullptr && a.dp_thresh == 0)) && !(a.dbg & 16)) return launch_gemm_nt256p<EPI>(a, st, stat_rows, dyn);
 #else
