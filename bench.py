@@ -473,16 +473,21 @@ def main():
     # one event per step boundary on the launch stream: min / median / max step time inside the timed region (the same
     # launch moves by +-10 % with the clock state of the box; the spread says how steady this run was)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    aux_default = eng.aux_stream_enabled
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         # the live per-kernel timing brackets each fc GEMM launch with two HIP events, and every event record idles
         # the queue for ~5 us (58 of them per step = 6 % of it): sample every --profile_every-th step
+        # The profiled step runs on ONE stream: with the second stream (cp_config.aux_stream) the floating weight gradients share the
+        # chip with the critical path's launches, and an event pair around a launch then times the contention too, not the kernel.
         if i % args.profile_every == 0:
             eng.profile_resume()
+            eng.aux_stream_enabled = False
         else:
             eng.profile_disable()
+            eng.aux_stream_enabled = aux_default
         step(args.warmup + i)
         marks[i + 1].record()
     barrier()
@@ -490,6 +495,7 @@ def main():
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     profiled_steps = len(range(0, args.steps, args.profile_every))
     eng.profile_disable()
+    eng.aux_stream_enabled = aux_default
     prof = eng.profile_summary()
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -557,7 +563,7 @@ def main():
                 if kname in k:
                     traffic = dict(value=v["hbm_bytes_per_launch"], source="profiles/" + os.path.basename(tpath) + " (PMC FETCH_SIZE / WRITE_SIZE passes, builder's box)")
         avg_s = ms / launches / 1e3
-        paired = 1 if eng._aux is not None else 2
+        paired = 2                  # (the profiled steps run on one stream: fc7+fc6 and fc5+fc4 share a launch each)
         byts, flops = gemm_model(dom, N, dt, args.dp_emg > 0, paired)
         gbs = byts / avg_s / 1e9
         tfl = flops / avg_s / 1e12
@@ -586,6 +592,11 @@ def main():
                     mfma_busy_frac=mfma_busy["value"] if mfma_busy else None, mfma_busy_source=mfma_busy["source"] if mfma_busy else None,
                     hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
                     gemm_ms_per_step={k: prof[k][0] / profiled_steps for k in gemm_kinds if k in prof},
+                    second_stream=bool(aux_default and eng._aux is not None),
+                    note="per-kernel durations: HIP events around each launch on the profiled steps, which run on ONE stream (kernel alone on the chip); "
+                         "the other timed steps float the off-critical-path weight gradients on cp_config.aux_stream, where a launch's wall time "
+                         "includes what it shares the chip with (profiles/r04_kernel_stats.csv = the default command, r04_serial_kernel_stats.csv = "
+                         "CPNATIVE_AUX_STREAM=0: the durations these figures agree with)",
                     profiled_steps=profiled_steps,
                     per_kernel=per_kernel)
         # the step as a whole against SURVEY 8d's byte model (51.3 KB per window in 16-bit storage, 102.5 in f32, 25.6 in 8-bit)

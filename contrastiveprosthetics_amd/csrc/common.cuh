@@ -179,14 +179,28 @@ __device__ __forceinline__ uint4 bn_drop_chunk(const uint4& in, const float* __r
 }
 
 // ---- BatchNorm totals as fixed-point integers (the small-batch path, small.cuh) --------------------------------------------
-// fixed-point scales of the accumulators: activation sums (|sum| up to ~2,624 x 10^6 for sums of squares) and gradient sums
-#define SM_ACT_SHIFT 31
+// fixed-point scales of the accumulators.  Activations: 2^-24 steps, legitimate totals below 2^30 (2,624 windows x 12 positions of
+// squares up to 3 x 10^4); gradients (small numbers: the loss carries 1 / (2 N)): 2^-40 steps, totals below 2^14.
+// Round 4: a partial sum that is not finite, or too large for that range, cannot be added as an integer (NaN would convert
+// to 0 and vanish from the statistics; a large value would wrap).  It adds the sentinel 2^56 instead: with at most 255 adds per total
+// (the small-batch launches have <= 164 workgroups) k sentinels stay in [2^56, 2^64) and never wrap to a small number, legitimate
+// sums stay below 2^54, so any total at or beyond 2^55 in magnitude reads back as NaN -- the statistics are poisoned, as the f32 sums
+// of the large-batch path are.
+#define SM_ACT_SHIFT 24
 #define SM_GRAD_SHIFT 40
+#define SM_ACC_SENTINEL (1ull << 56)
 __device__ __forceinline__ void sm_acc_add(long long* acc, float s, int shift) {
     // s * 2^shift is an integer-valued double wherever the f32's last bit is worth >= 2^-shift; smaller bits round away (<= 2^-shift)
-    atomicAdd((unsigned long long*)acc, (unsigned long long)__double2ll_rn((double)s * (double)(1ull << shift)));
+    const double d = (double)s * (double)(1ull << shift);
+    const unsigned long long q = fabs(d) < 18014398509481984.0 /* 2^54 */ ? (unsigned long long)__double2ll_rn(d) : SM_ACC_SENTINEL;
+    atomicAdd((unsigned long long*)acc, q);
 }
-__device__ __forceinline__ double sm_acc_get(const long long* acc, int shift) { return (double)*acc / (double)(1ull << shift); }
+__device__ __forceinline__ double sm_acc_get(const long long* acc, int shift) {
+    const long long v = *acc;
+    const unsigned long long mag = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    if (mag >= (1ull << 55)) return (double)__int_as_float(0x7fc00000);
+    return (double)v / (double)(1ull << shift);
+}
 
 struct SmBN {
     const long long* acc;    // [2][C] totals (sum, sum of squares) as fixed point, or nullptr: `stats` is already final (conv2's BatchNorm)
