@@ -477,6 +477,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     auto finalize = [&](int l, int nrows, double count) -> int {
+        if (!batch_stats) return 0;                       // evaluation with running statistics: all nine tables were written up front
         ProfScope ps(CP_K_BN_FINALIZE, st);
         const int C = kLayerC[l];
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
@@ -497,6 +498,16 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         ProfScope ps(CP_K_PREP, st);
         hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
         CKL("prep_conv2_kernel");
+        if (!batch_stats) {
+            BnRunningAll ra{};
+            for (int l = 0; l < CP_N_BN; ++l) {
+                ra.gamma[l] = p->bn_g[l]; ra.beta[l] = p->bn_b[l]; ra.mean[l] = bn->running_mean[l]; ra.var[l] = bn->running_var[l];
+                ra.stats[l] = stats(l); ra.C[l] = kLayerC[l];
+            }
+            ra.eps = c->bn_eps;
+            hipLaunchKernelGGL(bn_running_stats_kernel, dim3(CP_N_BN), dim3(512), 0, st, ra);
+            CKL("bn_running_stats_kernel");
+        }
         if (drop) {
             // the weights of the layers behind a dropout (fc5..fc7, projection) carry no BatchNorm fold: plain copies, all in one launch
             FoldBatch fb{};
@@ -636,6 +647,7 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
     Fp8State* fs = (Fp8State*)(base + w.f8state);
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     auto finalize = [&](int l, int nrows, double count, const int* unscale) -> int {
+        if (!batch_stats) return 0;                       // (encoder_forward_t: one launch wrote all nine tables)
         ProfScope ps(CP_K_BN_FINALIZE, st);
         const int C = kLayerC[l];
         const PreReduce pre{partials, (float*)(base + w.partials2), st};
@@ -656,6 +668,15 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
         ProfScope ps(CP_K_PREP, st);
         hipLaunchKernelGGL(fp8_update_scales_kernel, dim3(1), dim3(64), 0, st, fs, N);
         hipLaunchKernelGGL((prep_conv2_kernel<T>), dim3(48), dim3(256), 0, st, p->conv2_w, (T*)(base + w.wc2_f), (T*)(base + w.wc2_d));
+        if (!batch_stats) {
+            BnRunningAll ra{};
+            for (int l = 0; l < CP_N_BN; ++l) {
+                ra.gamma[l] = p->bn_g[l]; ra.beta[l] = p->bn_b[l]; ra.mean[l] = bn->running_mean[l]; ra.var[l] = bn->running_var[l];
+                ra.stats[l] = stats(l); ra.C[l] = kLayerC[l];
+            }
+            ra.eps = c->bn_eps;
+            hipLaunchKernelGGL(bn_running_stats_kernel, dim3(CP_N_BN), dim3(512), 0, st, ra);
+        }
         CKL("prep kernels (fp8)");
     }
     // conv1 (statistics only) and conv2 (output as e4m3)

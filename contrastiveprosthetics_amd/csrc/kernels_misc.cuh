@@ -123,6 +123,30 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------
+// Evaluation with stock BatchNorm (running statistics, code/models.py:238-243 in eval mode): the affine of EVERY layer is known
+// before the pass starts, so one launch writes all nine `stats` tables (round 4: nine bn_finalize launches -> one; the statistics
+// the GEMM epilogues still sum are not read).  grid CP_N_BN blocks of 512 threads.
+// ------------------------------------------------------------------------------------
+struct BnRunningAll {
+    const float* gamma[9];
+    const float* beta[9];
+    const float* mean[9];
+    const float* var[9];
+    float* stats[9];
+    int C[9];
+    float eps;
+};
+__global__ __launch_bounds__(512) void bn_running_stats_kernel(BnRunningAll a) {
+    const int l = blockIdx.x, c = threadIdx.x, C = a.C[l];
+    if (c >= C) return;
+    const float mean = a.mean[l][c], invstd = 1.0f / sqrtf(a.var[l][c] + a.eps), sc = a.gamma[l][c] * invstd;
+    a.stats[l][0 * C + c] = mean;
+    a.stats[l][1 * C + c] = invstd;
+    a.stats[l][2 * C + c] = sc;
+    a.stats[l][3 * C + c] = a.beta[l][c] - mean * sc;
+}
+
+// ------------------------------------------------------------------------------------
 // fold the previous BN's affine into a Linear:  y = (r*s + t) W^T + b = r (W diag s)^T + (b + W t)
 //   mode 0: k' = k, channel = k               (512-wide inputs)
 //   mode 1: input is the conv stack: source k = c*12 + w, stored k' = w*64 + c, channel = c
