@@ -1220,7 +1220,7 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
 // glove-angle class encoder
 // ---------------------------------------------------------------------------------------
 struct GWS {
-    size_t xp, w1p, h, a, w2p, w2t, dzg, gbuf, stats, coef, zeros, partials, partials2, slabs, total;
+    size_t xp, w1p, h, a, w2p, w2t, dzg, gbuf, stats, coef, zeros, partials, partials2, slabs, frags, total;
 };
 static const int kGlovePartialRows = 2048, kGloveSlabs = 128;
 
@@ -1246,6 +1246,7 @@ static GWS carve_glove(int64_t rows, int dtype) {
     g.partials = take((size_t)(tiles > kGlovePartialRows ? tiles : kGlovePartialRows) * 2 * GL_H * 4);
     g.partials2 = take((size_t)REDUCE_SLICES * 2048 * 4);
     g.slabs = take((size_t)kGloveSlabs * 64 * GL_H * 4);
+    g.frags = take((size_t)GLF_COUNT * 64 * 16);
     g.total = off;
     return g;
 }
@@ -1277,6 +1278,29 @@ static int glove_forward_t(const cp_config* c, const cp_glove_params* gp, const 
     T* av = (T*)(base + w.a);
     float* partials = (float*)(base + w.partials);
     float* stats = (float*)(base + w.stats);
+    if constexpr (sizeof(T) == 2) {
+        // 16-bit storage, round 4 (glove.cuh): the hidden layer is recomputed from the 20 inputs, never stored -- statistics, then
+        // relu(BN(.)) and the 256 -> 16 product in one kernel; no padded-K GEMM launches, no element-wise passes
+        GloveFusedArgs fa{};
+        fa.x = glove; fa.w1 = gp->w1; fa.w2 = gp->last_w; fa.stats = stats; fa.zg = zg; fa.partials = partials; fa.R = R;
+        fa.xp = c->training ? (bf16_t*)xp : nullptr;                      // (the weight gradient's operand: training only)
+        fa.frags = (const uint4*)(base + w.frags);
+        hipLaunchKernelGGL(glove_prep_kernel, dim3(GLF_COUNT), dim3(64), 0, st, gp->w1, gp->last_w, (uint4*)(base + w.frags));
+        const int64_t ntile = (R + 15) / 16;
+        int nrows = (int)(ntile < kGlovePartialRows ? ntile : kGlovePartialRows);
+        if (batch_stats) {
+            hipLaunchKernelGGL(glove_stats_kernel, dim3(nrows), dim3(256), 0, st, fa);
+            CKL("glove_stats_kernel");
+        }
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(FIN_GRID(GL_H)), dim3(FIN_THREADS), 0, st, partials, nrows, (double)R, gp->bn_g, gp->bn_b,
+                           have_running ? gp->running_mean : nullptr, have_running ? gp->running_var : nullptr, upd,
+                           batch_stats ? 0 : 1, c->bn_momentum, c->bn_eps, stats, GL_H);
+        CKL("bn_finalize_kernel(glove)");
+        const int gf = (int)((ntile + 3) / 4 < 2048 ? (ntile + 3) / 4 : 2048);
+        hipLaunchKernelGGL(glove_fwd_kernel, dim3(gf), dim3(256), 0, st, fa);
+        CKL("glove_fwd_kernel");
+        return 0;
+    }
     CK(hipMemsetAsync(base + w.zeros, 0, GL_H * 4, st));
     hipLaunchKernelGGL((pad_cast_kernel<T>), dim3(grid_rows(R * GL_KP, 256, 4096)), dim3(256), 0, st, glove, R, GL_IN, xp, R, GL_KP);
     hipLaunchKernelGGL((pad_cast_kernel<T>), dim3(64), dim3(256), 0, st, gp->w1, (int64_t)GL_H, GL_IN, (T*)(base + w.w1p), (int64_t)GL_H, GL_KP);
@@ -1367,6 +1391,44 @@ static int glove_backward_t(const cp_config* c, const cp_glove_params* gp, int64
     float* coef = (float*)(base + w.coef);
     const PreReduce pre{partials, (float*)(base + w.partials2), st};
     int S;
+    if constexpr (sizeof(T) == 2) {
+        // 16-bit storage, round 4 (glove.cuh): two recompute kernels around the coefficient launch -- the first reduces the
+        // BatchNorm-backward sums and writes a = relu(BN(h)), the second writes dL/dh; the two weight gradients then are the same
+        // TN products as before on those two tensors
+        GloveFusedArgs fa{};
+        fa.xp = (bf16_t*)xp; fa.w1 = gp->w1; fa.w2 = gp->last_w; fa.stats = stats; fa.coef = coef; fa.dzg = (const bf16_t*)dzg;
+        fa.a_out = (bf16_t*)av; fa.dh_out = (bf16_t*)gbuf; fa.partials = partials; fa.R = R;
+        fa.frags = (const uint4*)(base + w.frags);                          // (made by the forward pass: the weights have not moved since)
+        const int64_t ntile = (R + 15) / 16;
+        const int nb = (int)(ntile < kGlovePartialRows ? ntile : kGlovePartialRows);
+        hipLaunchKernelGGL(glove_bwd_kernel<0>, dim3(nb), dim3(256), 0, st, fa);
+        CKL("glove_bwd_kernel<0>");
+        {
+            GemmTNArgs ta{};
+            ta.X = dzg; ta.ldx = 64; ta.Y = av; ta.ldy = GL_H; ta.slabs = slabs; ta.M = R; ta.P = 64; ta.Q = GL_H;
+            split_rows(R, kGloveSlabs, &S, &ta.rows_per_split);
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, CP_D_E, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, g->last_w, 0, (float*)nullptr);
+            CKL("reduce_slabs(glove last)");
+        }
+        int nr = nb;
+        const float* pp = pre(nr, 2 * GL_H);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(GL_H)), dim3(FIN_THREADS), 0, st, pp, nr, (double)R, stats, coef, g->bn_g, g->bn_b, GL_H, 1);
+        CKL("bn_bwd_finalize_kernel(glove)");
+        hipLaunchKernelGGL(glove_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, fa);
+        CKL("glove_bwd_kernel<1>");
+        {
+            GemmTNArgs ta{};
+            ta.X = xp; ta.ldx = GL_KP; ta.Y = gbuf; ta.ldy = GL_H; ta.slabs = slabs; ta.M = R; ta.P = 64; ta.Q = GL_H;
+            split_rows(R, kGloveSlabs, &S, &ta.rows_per_split);
+            CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, GL_IN, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, g->w1, 3, (float*)nullptr);
+            CKL("reduce_slabs(glove w1)");
+        }
+        return 0;
+    }
     // last: dW2 = dzg^T a   and   da = dzg W2
     hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(64), dim3(256), 0, st, gp->last_w, (T*)(base + w.w2t), CP_D_E, GL_H, 64, 0);
     CKL("transpose_w_kernel(glove)");

@@ -101,3 +101,253 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* __restrict__ g, co
         *(uint4*)(g + i * EPC) = D::pack(gv);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 4, 16-bit storage: the hidden layer is never stored.  Its input is 20 numbers per row, so
+// h = x W1^T (256 values) is ONE v_mfma_f32_16x16x32_bf16 per 16 features x 16 rows (K = 20 zero-padded to 32) and is recomputed by
+// every kernel that needs it -- four kernels instead of the generic K-padded GEMM launches and the element-wise passes between them:
+//   glove_stats_kernel   h -> column sums (sum h, sum h^2) for BatchNorm; writes the padded bf16 copy of x the weight gradient reads
+//   glove_fwd_kernel     h -> a = relu(BN(h)) -> zg = a W2^T (a stays in registers: it IS the second product's B operand)
+//   glove_bwd_kernel<0>  h, da = dzg W2, g = [BN(h) > 0] da -> column sums (sum g, sum g h); writes a (operand of dW2 = dzg^T a)
+//   glove_bwd_kernel<1>  the same again with the coefficients final: dh = ca g + cb h + cz, written (operand of dW1^T = x^T dh)
+// Lane map of every 16 x 16 tile (gemm_ws16_kernel's): weights are the MFMA A operand, rows the B operand; a lane (q4 = lane >> 4,
+// s16 = lane & 15) ends with features 16 ft + 4 q4 + e (e = 0..3) of row 16 tile + s16.  The contraction index of a product may be
+// permuted as long as both operands agree, so the second product takes a lane's own 8 values of feature tiles 2 kb, 2 kb + 1 as its
+// k block and W2 is loaded in that order -- no cross-lane traffic between the two products.
+// stats / bwd kernels: the 4 waves of a workgroup split the FEATURES (4 tiles each) over the same rows; fwd: they split the ROWS.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct GloveFusedArgs {
+    const float* x;          // [R][20] f32
+    const float* w1;         // glove_net.linear.1.weight [256][20] f32
+    const float* w2;         // glove_net.last.0.weight [16][256] f32
+    const float* stats;      // [4][256] mean, invstd, scale, shift of the BatchNorm (fwd, bwd)
+    const float* coef;       // [3][256] BatchNorm-backward coefficients (bwd<1>)
+    const bf16_t* dzg;       // [R][64] dL/dzg, 16 live columns (bwd)
+    float* zg;               // [R][16] f32 (fwd)
+    bf16_t* xp;              // [R][64] bf16 copy of x, zero padded (stats writes it -- nullptr: not wanted; the bwd kernels READ it: the same rounded
+                             // inputs as the forward pass saw, and cp_glove_backward is not handed x again)
+    bf16_t* a_out;           // [R][256] (bwd<0>)
+    bf16_t* dh_out;          // [R][256] (bwd<1>)
+    float* partials;         // [gridDim.x][2][256]
+    const uint4* frags;      // the weights in MFMA-fragment order, bf16, one 16-byte chunk per lane (glove_prep_kernel): [GLF_W1 + ft][64] =
+                             // W1 tile ft, [GLF_W2 + kb][64] = W2 k block kb (fwd), [GLF_W2T + ft][64] = W2^T tile ft (bwd)
+    int64_t R;
+};
+enum { GLF_W1 = 0, GLF_W2 = 16, GLF_W2T = 24, GLF_COUNT = 40 };
+
+__device__ __forceinline__ s16x8 glove_pack8(const float (&v)[8]) {
+    const uint4 c = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    return __builtin_bit_cast(s16x8, c);
+}
+// B operand of h's product for one 16-row tile: lane (row s16, k group q4) supplies x[row][8 q4 .. +7] (k >= 20, rows >= R: 0)
+__device__ __forceinline__ s16x8 glove_x_frag(const float* __restrict__ x, int64_t row, int64_t R, int q4) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < R && q4 < 3) {
+        const float4 lo = *(const float4*)(x + row * GL_IN + 8 * q4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+        if (q4 < 2) {
+            const float4 hi = *(const float4*)(x + row * GL_IN + 8 * q4 + 4);
+            v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        }
+    }
+    return glove_pack8(v);
+}
+// A operand of h's product for feature tile ft: lane (feature s16, k group q4) supplies W1[16 ft + s16][8 q4 .. +7]
+__device__ __forceinline__ s16x8 glove_w1_frag(const float* __restrict__ w1, int ft, int s16, int q4) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (8 * q4 + i < GL_IN) ? w1[(ft * 16 + s16) * GL_IN + 8 * q4 + i] : 0.f;
+    return glove_pack8(v);
+}
+typedef __attribute__((ext_vector_type(4))) float gl_f32x4;
+__device__ __forceinline__ gl_f32x4 glove_mfma(const s16x8& a, const s16x8& b, const gl_f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// the three weight operands in fragment order, once per pass (the kernels' own prologues then are 4-16 16-byte loads per lane instead
+// of 64-192 scalar loads + conversions in every one of thousands of waves): grid GLF_COUNT blocks of 64 threads
+__global__ __launch_bounds__(64) void glove_prep_kernel(const float* __restrict__ w1, const float* __restrict__ w2, uint4* __restrict__ frags) {
+    const int lane = threadIdx.x, s16 = lane & 15, q4 = lane >> 4, b = blockIdx.x;
+    s16x8 f;
+    if (b < GLF_W2) {
+        f = glove_w1_frag(w1, b - GLF_W1, s16, q4);
+    } else if (b < GLF_W2T) {           // lane (output j = s16, k group q4): W2[j][the 8 features lane group q4 holds of tiles 2 kb, 2 kb + 1]
+        const int kb = b - GLF_W2;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w2[s16 * GL_H + (2 * kb + (i >> 2)) * 16 + 4 * q4 + (i & 3)];
+        f = glove_pack8(v);
+    } else {                            // lane (feature s16 of tile ft, k group q4): W2[j = 8 q4 .. +7][16 ft + s16], j < 16
+        const int ft = b - GLF_W2T;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = q4 < 2 ? w2[(8 * q4 + i) * GL_H + ft * 16 + s16] : 0.f;
+        f = glove_pack8(v);
+    }
+    frags[b * 64 + lane] = __builtin_bit_cast(uint4, f);
+}
+__device__ __forceinline__ s16x8 glove_frag(const uint4* __restrict__ frags, int idx, int lane) {
+    return __builtin_bit_cast(s16x8, frags[idx * 64 + lane]);
+}
+
+__global__ __launch_bounds__(256) void glove_stats_kernel(GloveFusedArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s16 = lane & 15, q4 = lane >> 4;
+    s16x8 w1f[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w1f[t] = glove_frag(a.frags, GLF_W1 + 4 * wave + t, lane);
+    float s1[4][4], s2[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[t][e] = s2[t][e] = 0.f;
+    const int64_t ntile = (a.R + 15) / 16;
+    const gl_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    s16x8 xnext = glove_x_frag(a.x, (int64_t)blockIdx.x * 16 + s16, a.R, q4);       // (the next tile's inputs are in flight under this tile's arithmetic)
+    for (int64_t rt = blockIdx.x; rt < ntile; rt += gridDim.x) {
+        const int64_t row = rt * 16 + s16;
+        const s16x8 xf = xnext;
+        xnext = glove_x_frag(a.x, row + (int64_t)gridDim.x * 16, a.R, q4);
+        if (a.xp != nullptr && row < a.R && wave < 2)           // wave 0: columns 0..31 = this fragment; wave 1: columns 32..63 = 0
+            *(uint4*)(a.xp + row * GL_KP + 32 * wave + 8 * q4) = wave == 0 ? __builtin_bit_cast(uint4, xf) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const gl_f32x4 h = glove_mfma(w1f[t], xf, zero);      // rows past the end have x = 0: h = 0, nothing added
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[t][e] += h[e]; s2[t][e] = fmaf(h[e], h[e], s2[t][e]); }
+        }
+    }
+    // totals over the 16 rows of the lane group; lane s16 < 8 of group q4 ends with value s16 = 4 (tile & 1) + e
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float v1[8], v2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v1[i] = s1[2 * half + (i >> 2)][i & 3]; v2[i] = s2[2 * half + (i >> 2)][i & 3]; }
+        const float r1 = row16_fold8(v1, lane), r2 = row16_fold8(v2, lane);
+        if (s16 < 8) {
+            const int f = (4 * wave + 2 * half + (s16 >> 2)) * 16 + 4 * q4 + (s16 & 3);
+            a.partials[((int64_t)blockIdx.x * 2 + 0) * GL_H + f] = r1;
+            a.partials[((int64_t)blockIdx.x * 2 + 1) * GL_H + f] = r2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void glove_fwd_kernel(GloveFusedArgs a) {
+    __shared__ float sc_s[GL_H], sh_s[GL_H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s16 = lane & 15, q4 = lane >> 4;
+    sc_s[tid] = a.stats[2 * GL_H + tid];
+    sh_s[tid] = a.stats[3 * GL_H + tid];
+    s16x8 w1f[16], w2f[8];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w1f[t] = glove_frag(a.frags, GLF_W1 + t, lane);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) w2f[kb] = glove_frag(a.frags, GLF_W2 + kb, lane);
+    __syncthreads();
+    const int64_t ntile = (a.R + 15) / 16;
+    const gl_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    s16x8 xnext = glove_x_frag(a.x, ((int64_t)blockIdx.x * 4 + wave) * 16 + s16, a.R, q4);
+    for (int64_t rt = (int64_t)blockIdx.x * 4 + wave; rt < ntile; rt += (int64_t)gridDim.x * 4) {
+        const int64_t row = rt * 16 + s16;
+        const s16x8 xf = xnext;
+        xnext = glove_x_frag(a.x, row + (int64_t)gridDim.x * 64, a.R, q4);
+        gl_f32x4 z = zero;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            float v[8];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int t = 2 * kb + o;
+                const gl_f32x4 h = glove_mfma(w1f[t], xf, zero);
+                const float4 sc = *(const float4*)(sc_s + t * 16 + 4 * q4), sh = *(const float4*)(sh_s + t * 16 + 4 * q4);
+                v[4 * o + 0] = fmaxf(fmaf(sc.x, h[0], sh.x), 0.f);
+                v[4 * o + 1] = fmaxf(fmaf(sc.y, h[1], sh.y), 0.f);
+                v[4 * o + 2] = fmaxf(fmaf(sc.z, h[2], sh.z), 0.f);
+                v[4 * o + 3] = fmaxf(fmaf(sc.w, h[3], sh.w), 0.f);
+            }
+            z = glove_mfma(w2f[kb], glove_pack8(v), z);
+        }
+        if (row < a.R) *(float4*)(a.zg + row * 16 + 4 * q4) = make_float4(z[0], z[1], z[2], z[3]);     // zg[row][j = 4 q4 + e]
+    }
+}
+
+// PASS 0: sums + a;  PASS 1: dh
+template <int PASS>
+__global__ __launch_bounds__(256) void glove_bwd_kernel(GloveFusedArgs a) {
+    __shared__ float sc_s[GL_H], sh_s[GL_H], cf_s[3][GL_H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s16 = lane & 15, q4 = lane >> 4;
+    sc_s[tid] = a.stats[2 * GL_H + tid];
+    sh_s[tid] = a.stats[3 * GL_H + tid];
+    if (PASS == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cf_s[c][tid] = a.coef[c * GL_H + tid];
+    }
+    s16x8 w1f[4], w2t[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        w1f[t] = glove_frag(a.frags, GLF_W1 + 4 * wave + t, lane);
+        w2t[t] = glove_frag(a.frags, GLF_W2T + 4 * wave + t, lane);
+    }
+    __syncthreads();
+    float s1[4][4], s2[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[t][e] = s2[t][e] = 0.f;
+    const int64_t ntile = (a.R + 15) / 16;
+    const gl_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);          // (gemm_ws16_kernel: the 8 features a lane owns of a 32-feature pair after the swap)
+    bf16_t* out = PASS == 0 ? a.a_out : a.dh_out;
+    // lane (row s16, k group q4): x[row][8 q4 .. +7] from the padded copy, dzg[row][8 q4 .. +7] (16 live columns); the next tile's are
+    // requested before this tile's arithmetic
+    auto load_x = [&](int64_t row) { return row < a.R ? *(const uint4*)(a.xp + row * GL_KP + 8 * q4) : make_uint4(0, 0, 0, 0); };
+    auto load_dz = [&](int64_t row) { return (row < a.R && q4 < 2) ? *(const uint4*)(a.dzg + row * 64 + 8 * q4) : make_uint4(0, 0, 0, 0); };
+    uint4 xn = load_x((int64_t)blockIdx.x * 16 + s16), dn = load_dz((int64_t)blockIdx.x * 16 + s16);
+    for (int64_t rt = blockIdx.x; rt < ntile; rt += gridDim.x) {
+        const int64_t row = rt * 16 + s16;
+        const s16x8 xf = __builtin_bit_cast(s16x8, xn), dzf = __builtin_bit_cast(s16x8, dn);
+        xn = load_x(row + (int64_t)gridDim.x * 16);
+        dn = load_dz(row + (int64_t)gridDim.x * 16);
+        uint2 pk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const gl_f32x4 h = glove_mfma(w1f[t], xf, zero);
+            const gl_f32x4 da = glove_mfma(w2t[t], dzf, zero);
+            const int f = (4 * wave + t) * 16 + 4 * q4;
+            const float4 sc = *(const float4*)(sc_s + f), sh = *(const float4*)(sh_s + f);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bn = fmaf(scv[e], h[e], shv[e]);
+                const float g = bn > 0.f ? da[e] : 0.f;
+                if (PASS == 0) {
+                    s1[t][e] += g;
+                    s2[t][e] = fmaf(g, h[e], s2[t][e]);
+                    o[e] = fmaxf(bn, 0.f);
+                } else {
+                    o[e] = fmaf(cf_s[0][f + e], g, fmaf(cf_s[1][f + e], h[e], cf_s[2][f + e]));
+                }
+            }
+            pk[t] = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        }
+#pragma unroll
+        for (int fp = 0; fp < 2; ++fp) {
+            const auto sx = __builtin_amdgcn_permlane16_swap(pk[2 * fp].x, pk[2 * fp + 1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(pk[2 * fp].y, pk[2 * fp + 1].y, false, false);
+            if (row < a.R) *(uint4*)(out + row * GL_H + (4 * wave + 2 * fp) * 16 + foff) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float v1[8], v2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v1[i] = s1[2 * half + (i >> 2)][i & 3]; v2[i] = s2[2 * half + (i >> 2)][i & 3]; }
+            const float r1 = row16_fold8(v1, lane), r2 = row16_fold8(v2, lane);
+            if (s16 < 8) {
+                const int f = (4 * wave + 2 * half + (s16 >> 2)) * 16 + 4 * q4 + (s16 & 3);
+                a.partials[((int64_t)blockIdx.x * 2 + 0) * GL_H + f] = r1;
+                a.partials[((int64_t)blockIdx.x * 2 + 1) * GL_H + f] = r2;
+            }
+        }
+    }
+}
