@@ -1223,6 +1223,7 @@ struct GWS {
     size_t xp, w1p, h, a, w2p, w2t, dzg, gbuf, stats, coef, zeros, partials, partials2, slabs, frags, total;
 };
 static const int kGlovePartialRows = 2048, kGloveSlabs = 128;
+static const int kGloveBwdBlocks = 512;       // workgroups (= f32 weight-gradient slabs of up to 32 KiB) of the fused glove backward kernels
 
 // (CP_FP8 configurations run the glove-angle class encoder -- 0.3 % of the step's FLOPs, K = 20 -- on the bf16 kernels: 8-bit storage
 //  is for the sEMG encoder's activations)
@@ -1245,7 +1246,8 @@ static GWS carve_glove(int64_t rows, int dtype) {
     const int64_t tiles = (rows + 127) / 128;
     g.partials = take((size_t)(tiles > kGlovePartialRows ? tiles : kGlovePartialRows) * 2 * GL_H * 4);
     g.partials2 = take((size_t)REDUCE_SLICES * 2048 * 4);
-    g.slabs = take((size_t)kGloveSlabs * 64 * GL_H * 4);
+    g.slabs = take((size_t)kGloveSlabs * 64 * GL_H * 4 > (size_t)kGloveBwdBlocks * GL_H * 32 * 4 ? (size_t)kGloveSlabs * 64 * GL_H * 4
+                                                                                                  : (size_t)kGloveBwdBlocks * GL_H * 32 * 4);
     g.frags = take((size_t)GLF_COUNT * 64 * 16);
     g.total = off;
     return g;
@@ -1393,40 +1395,25 @@ static int glove_backward_t(const cp_config* c, const cp_glove_params* gp, int64
     int S;
     if constexpr (sizeof(T) == 2) {
         // 16-bit storage, round 4 (glove.cuh): two recompute kernels around the coefficient launch -- the first reduces the
-        // BatchNorm-backward sums and writes a = relu(BN(h)), the second writes dL/dh; the two weight gradients then are the same
-        // TN products as before on those two tensors
+        // BatchNorm-backward sums and forms dW2 = dzg^T relu(BN(h)), the second forms dW1 = (dL/dh)^T x; both weight gradients run on the
+        // matrix pipe inside them (per-workgroup f32 slabs, summed in fixed order) and no row-sized tensor is written
         GloveFusedArgs fa{};
         fa.xp = (bf16_t*)xp; fa.w1 = gp->w1; fa.w2 = gp->last_w; fa.stats = stats; fa.coef = coef; fa.dzg = (const bf16_t*)dzg;
-        fa.a_out = (bf16_t*)av; fa.dh_out = (bf16_t*)gbuf; fa.partials = partials; fa.R = R;
+        fa.slabs = slabs; fa.partials = partials; fa.R = R;
         fa.frags = (const uint4*)(base + w.frags);                          // (made by the forward pass: the weights have not moved since)
-        const int64_t ntile = (R + 15) / 16;
-        const int nb = (int)(ntile < kGlovePartialRows ? ntile : kGlovePartialRows);
+        const int64_t npair = (R + 31) / 32;
+        const int nb = (int)(npair < kGloveBwdBlocks ? npair : kGloveBwdBlocks);
         hipLaunchKernelGGL(glove_bwd_kernel<0>, dim3(nb), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(glove_reduce_kernel, dim3(CP_D_E * GL_H / 64), dim3(256), 0, st, slabs, nb, CP_D_E, GL_H, GL_H, g->last_w);
         CKL("glove_bwd_kernel<0>");
-        {
-            GemmTNArgs ta{};
-            ta.X = dzg; ta.ldx = 64; ta.Y = av; ta.ldy = GL_H; ta.slabs = slabs; ta.M = R; ta.P = 64; ta.Q = GL_H;
-            split_rows(R, kGloveSlabs, &S, &ta.rows_per_split);
-            CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, CP_D_E, (const float*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, g->last_w, 0, (float*)nullptr);
-            CKL("reduce_slabs(glove last)");
-        }
         int nr = nb;
         const float* pp = pre(nr, 2 * GL_H);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(FIN_GRID(GL_H)), dim3(FIN_THREADS), 0, st, pp, nr, (double)R, stats, coef, g->bn_g, g->bn_b, GL_H, 1);
         CKL("bn_bwd_finalize_kernel(glove)");
         hipLaunchKernelGGL(glove_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(glove_reduce_kernel, dim3((GL_H * GL_IN + 63) / 64), dim3(256), 0, st, slabs, nb, GL_H, 32, GL_IN, g->w1);
         CKL("glove_bwd_kernel<1>");
-        {
-            GemmTNArgs ta{};
-            ta.X = xp; ta.ldx = GL_KP; ta.Y = gbuf; ta.ldy = GL_H; ta.slabs = slabs; ta.M = R; ta.P = 64; ta.Q = GL_H;
-            split_rows(R, kGloveSlabs, &S, &ta.rows_per_split);
-            CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, GL_IN, (const float*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, g->w1, 3, (float*)nullptr);
-            CKL("reduce_slabs(glove w1)");
-        }
+        (void)S; (void)av; (void)gbuf;
         return 0;
     }
     // last: dW2 = dzg^T a   and   da = dzg W2

@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* __restrict__ g, co
 // every kernel that needs it -- four kernels instead of the generic K-padded GEMM launches and the element-wise passes between them:
 //   glove_stats_kernel   h -> column sums (sum h, sum h^2) for BatchNorm; writes the padded bf16 copy of x the weight gradient reads
 //   glove_fwd_kernel     h -> a = relu(BN(h)) -> zg = a W2^T (a stays in registers: it IS the second product's B operand)
-//   glove_bwd_kernel<0>  h, da = dzg W2, g = [BN(h) > 0] da -> column sums (sum g, sum g h); writes a (operand of dW2 = dzg^T a)
-//   glove_bwd_kernel<1>  the same again with the coefficients final: dh = ca g + cb h + cz, written (operand of dW1^T = x^T dh)
+//   glove_bwd_kernel<0>  h, da = dzg W2, g = [BN(h) > 0] da -> column sums (sum g, sum g h) and dW2 = dzg^T relu(BN(h)), on the matrix pipe
+//   glove_bwd_kernel<1>  the same again with the coefficients final: dh = ca g + cb h + cz -> dW1 = dh^T x, on the matrix pipe
 // Lane map of every 16 x 16 tile (gemm_ws16_kernel's): weights are the MFMA A operand, rows the B operand; a lane (q4 = lane >> 4,
 // s16 = lane & 15) ends with features 16 ft + 4 q4 + e (e = 0..3) of row 16 tile + s16.  The contraction index of a product may be
 // permuted as long as both operands agree, so the second product takes a lane's own 8 values of feature tiles 2 kb, 2 kb + 1 as its
@@ -126,8 +126,7 @@ struct GloveFusedArgs {
     float* zg;               // [R][16] f32 (fwd)
     bf16_t* xp;              // [R][64] bf16 copy of x, zero padded (stats writes it -- nullptr: not wanted; the bwd kernels READ it: the same rounded
                              // inputs as the forward pass saw, and cp_glove_backward is not handed x again)
-    bf16_t* a_out;           // [R][256] (bwd<0>)
-    bf16_t* dh_out;          // [R][256] (bwd<1>)
+    float* slabs;            // (bwd) one weight-gradient slab per workgroup: <0> [16][256] (dW2), <1> [256][32] (dW1, k padded)
     float* partials;         // [gridDim.x][2][256]
     const uint4* frags;      // the weights in MFMA-fragment order, bf16, one 16-byte chunk per lane (glove_prep_kernel): [GLF_W1 + ft][64] =
                              // W1 tile ft, [GLF_W2 + kb][64] = W2 k block kb (fwd), [GLF_W2T + ft][64] = W2^T tile ft (bwd)
@@ -269,85 +268,158 @@ __global__ __launch_bounds__(256) void glove_fwd_kernel(GloveFusedArgs a) {
     }
 }
 
-// PASS 0: sums + a;  PASS 1: dh
+// Backward, both passes, in the TRANSPOSED tile orientation: rows are the MFMA's A operand and the weights its B operand, so a lane
+// (q4, s16) ends with rows 4 q4 + e (e = 0..3) of a 16-row tile for ONE feature 16 ft + s16.  In that orientation a lane's own 8 values of
+// two consecutive row tiles (32 rows) are exactly one A / B fragment of a product that contracts over ROWS -- the two weight gradients
+//     dW2[j][f]  = sum_rows dzg[row][j] a[row][f]      (PASS 0: a = relu(BN(h)), its B operand; A = 8 scalars of column j of dzg)
+//     dW1[f][k]  = sum_rows dh[row][f] x[row][k]       (PASS 1: dh, its A operand; B = 8 scalars of column k of the padded x)
+// run on the matrix pipe inside the recompute kernels and NO row-sized tensor is written by the backward pass at all (the first form of
+// this round wrote a and dL/dh, 86 MB each, for two generic TN launches: 41 + 30 + 2 x 31 + 2 x 11 us; this one: see DESIGN.md 7e).
+// PASS 0 also reduces the two BatchNorm-backward sums (sum g, sum g h; g = [BN(h) > 0] dzg W2).  Per workgroup: the 4 waves split the
+// features (4 tiles each), all walk the same row pairs; f32 slabs per workgroup, summed by glove_reduce_kernel (fixed order: reproducible).
+// rows past the end: x = 0 and dzg = 0 there, so h = 0, g = 0 and both products receive zeros.
 template <int PASS>
 __global__ __launch_bounds__(256) void glove_bwd_kernel(GloveFusedArgs a) {
-    __shared__ float sc_s[GL_H], sh_s[GL_H], cf_s[3][GL_H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s16 = lane & 15, q4 = lane >> 4;
-    sc_s[tid] = a.stats[2 * GL_H + tid];
-    sh_s[tid] = a.stats[3 * GL_H + tid];
-    if (PASS == 1) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) cf_s[c][tid] = a.coef[c * GL_H + tid];
-    }
-    s16x8 w1f[4], w2t[4];
+    s16x8 w1b[4], w2b[4];
+    float sc[4], sh[4], ca[4], cb[4], cz[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        w1f[t] = glove_frag(a.frags, GLF_W1 + 4 * wave + t, lane);
-        w2t[t] = glove_frag(a.frags, GLF_W2T + 4 * wave + t, lane);
+        const int f = (4 * wave + t) * 16 + s16;
+        w1b[t] = glove_frag(a.frags, GLF_W1 + 4 * wave + t, lane);         // lane (feature s16, k group q4): W1[f][8 q4 .. +7]
+        w2b[t] = glove_frag(a.frags, GLF_W2T + 4 * wave + t, lane);        // lane (feature s16, k group q4): W2[j = 8 q4 .. +7][f]
+        sc[t] = a.stats[2 * GL_H + f];
+        sh[t] = a.stats[3 * GL_H + f];
+        if (PASS == 1) { ca[t] = a.coef[f]; cb[t] = a.coef[GL_H + f]; cz[t] = a.coef[2 * GL_H + f]; }
     }
-    __syncthreads();
-    float s1[4][4], s2[4][4];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const gl_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    gl_f32x4 acc[4][PASS == 0 ? 1 : 2];        // PASS 0: dW2 tile [16 j][16 f] per feature tile; PASS 1: dW1 tiles [16 f][16 k] x 2 k tiles
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s1[t][e] = s2[t][e] = 0.f;
-    const int64_t ntile = (a.R + 15) / 16;
-    const gl_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);          // (gemm_ws16_kernel: the 8 features a lane owns of a 32-feature pair after the swap)
-    bf16_t* out = PASS == 0 ? a.a_out : a.dh_out;
-    // lane (row s16, k group q4): x[row][8 q4 .. +7] from the padded copy, dzg[row][8 q4 .. +7] (16 live columns); the next tile's are
-    // requested before this tile's arithmetic
+        for (int q = 0; q < (PASS == 0 ? 1 : 2); ++q) acc[t][q] = zero;
+    const int64_t npair = (a.R + 31) / 32;
+    // A operands of the two recompute products for row tile u of a pair: lane (row s16, k group q4) -> 16 bytes of its row
     auto load_x = [&](int64_t row) { return row < a.R ? *(const uint4*)(a.xp + row * GL_KP + 8 * q4) : make_uint4(0, 0, 0, 0); };
     auto load_dz = [&](int64_t row) { return (row < a.R && q4 < 2) ? *(const uint4*)(a.dzg + row * 64 + 8 * q4) : make_uint4(0, 0, 0, 0); };
-    uint4 xn = load_x((int64_t)blockIdx.x * 16 + s16), dn = load_dz((int64_t)blockIdx.x * 16 + s16);
-    for (int64_t rt = blockIdx.x; rt < ntile; rt += gridDim.x) {
-        const int64_t row = rt * 16 + s16;
-        const s16x8 xf = __builtin_bit_cast(s16x8, xn), dzf = __builtin_bit_cast(s16x8, dn);
-        xn = load_x(row + (int64_t)gridDim.x * 16);
-        dn = load_dz(row + (int64_t)gridDim.x * 16);
-        uint2 pk[4];
+    // The gathered operand of the weight-gradient product -- for the lane's column c the 8 rows {4 q4 + e, 16 + 4 q4 + e} of the pair --
+    // is a transpose of what the wave already holds (its 16-byte row chunks): through a wave-private LDS tile (rows padded to 68 bytes,
+    // so the four lane groups' rows fall on different banks).  (First version: 8-16 two-byte global loads per lane and pair -- 40-44 us.)
+    __shared__ unsigned short tr_s[4][32][34];
+    unsigned short (*tr)[34] = tr_s[wave];
+    auto put_rows = [&](const uint4 (&v)[2]) {          // lane (row s16, k group q4) stores columns 8 q4 .. +7 of rows s16, 16 + s16
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            uint32_t* d = (uint32_t*)&tr[16 * u + s16][8 * q4];
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+    };
+    auto get_col = [&](int c) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r0 = (i >> 1) * 16 + 4 * q4 + 2 * (i & 1);
+            w[i] = (uint32_t)tr[r0][c] | ((uint32_t)tr[r0 + 1][c] << 16);
+        }
+        return __builtin_bit_cast(s16x8, make_uint4(w[0], w[1], w[2], w[3]));
+    };
+    int64_t rp = blockIdx.x;
+    uint4 xn[2], dn[2];
+    auto fetch = [&](int64_t pair) {
+        const int64_t row0 = pair * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { xn[u] = load_x(row0 + 16 * u + s16); dn[u] = load_dz(row0 + 16 * u + s16); }
+    };
+    if (rp < npair) fetch(rp);
+    for (; rp < npair; rp += gridDim.x) {
+        s16x8 xa[2], dza[2], gop[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { xa[u] = __builtin_bit_cast(s16x8, xn[u]); dza[u] = __builtin_bit_cast(s16x8, dn[u]); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // (the previous pair's column reads are done before the tile is rewritten)
+        if (PASS == 0) { if (q4 < 2) put_rows(dn); }                       // dzg: 16 columns
+        else put_rows(xn);                                                  // x: 32 columns
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // a wave's LDS operations are in order: its own writes have landed
+        gop[0] = get_col(s16);                                              // PASS 0: column j = s16 of dzg; PASS 1: column k = s16 of x
+        if (PASS == 1) gop[1] = get_col(16 + s16);
+        if (rp + gridDim.x < npair) fetch(rp + gridDim.x);                 // the next pair's inputs are in flight under this pair's arithmetic
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const gl_f32x4 h = glove_mfma(w1f[t], xf, zero);
-            const gl_f32x4 da = glove_mfma(w2t[t], dzf, zero);
-            const int f = (4 * wave + t) * 16 + 4 * q4;
-            const float4 sc = *(const float4*)(sc_s + f), sh = *(const float4*)(sh_s + f);
-            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-            float o[4];
+            float o[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float bn = fmaf(scv[e], h[e], shv[e]);
-                const float g = bn > 0.f ? da[e] : 0.f;
-                if (PASS == 0) {
-                    s1[t][e] += g;
-                    s2[t][e] = fmaf(g, h[e], s2[t][e]);
-                    o[e] = fmaxf(bn, 0.f);
-                } else {
-                    o[e] = fmaf(cf_s[0][f + e], g, fmaf(cf_s[1][f + e], h[e], cf_s[2][f + e]));
+            for (int u = 0; u < 2; ++u) {
+                const gl_f32x4 h = glove_mfma(xa[u], w1b[t], zero);          // rows 16 u + 4 q4 + e, feature 16 (4 wave + t) + s16
+                const gl_f32x4 da = glove_mfma(dza[u], w2b[t], zero);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bn = fmaf(sc[t], h[e], sh[t]);
+                    const float g = bn > 0.f ? da[e] : 0.f;
+                    if (PASS == 0) {
+                        s1[t] += g;
+                        s2[t] = fmaf(g, h[e], s2[t]);
+                        o[4 * u + e] = fmaxf(bn, 0.f);
+                    } else {
+                        o[4 * u + e] = fmaf(ca[t], g, fmaf(cb[t], h[e], cz[t]));
+                    }
                 }
             }
-            pk[t] = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-        }
+            const s16x8 own = glove_pack8(o);            // 8 rows of the pair for this lane's feature: a fragment of the row-contracting product
+            if (PASS == 0) {
+                acc[t][0] = glove_mfma(gop[0], own, acc[t][0]);             // A = dzg^T (j = s16), B = a: [16 j][16 f]
+            } else {
 #pragma unroll
-        for (int fp = 0; fp < 2; ++fp) {
-            const auto sx = __builtin_amdgcn_permlane16_swap(pk[2 * fp].x, pk[2 * fp + 1].x, false, false);
-            const auto sy = __builtin_amdgcn_permlane16_swap(pk[2 * fp].y, pk[2 * fp + 1].y, false, false);
-            if (row < a.R) *(uint4*)(out + row * GL_H + (4 * wave + 2 * fp) * 16 + foff) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        }
-    }
-    if (PASS == 0) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float v1[8], v2[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { v1[i] = s1[2 * half + (i >> 2)][i & 3]; v2[i] = s2[2 * half + (i >> 2)][i & 3]; }
-            const float r1 = row16_fold8(v1, lane), r2 = row16_fold8(v2, lane);
-            if (s16 < 8) {
-                const int f = (4 * wave + 2 * half + (s16 >> 2)) * 16 + 4 * q4 + (s16 & 3);
-                a.partials[((int64_t)blockIdx.x * 2 + 0) * GL_H + f] = r1;
-                a.partials[((int64_t)blockIdx.x * 2 + 1) * GL_H + f] = r2;
+                for (int q = 0; q < 2; ++q) acc[t][PASS == 0 ? 0 : q] = glove_mfma(own, gop[q], acc[t][PASS == 0 ? 0 : q]);      // A = dh^T (f = s16), B = x: [16 f][16 k]
             }
         }
     }
+    // this workgroup's slab
+    if (PASS == 0) {
+        float* slab = a.slabs + (int64_t)blockIdx.x * (16 * GL_H);           // [16 j][256 f]: element (j = 4 q4 + e, f = tile * 16 + s16)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slab[(4 * q4 + e) * GL_H + (4 * wave + t) * 16 + s16] = acc[t][0][e];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                                    // column sums: this lane's rows, then the 4 lane groups
+            float v1 = s1[t], v2 = s2[t];
+            v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
+            v2 += __shfl_xor(v2, 16, 64); v2 += __shfl_xor(v2, 32, 64);
+            if (q4 == 0) {
+                const int f = (4 * wave + t) * 16 + s16;
+                a.partials[((int64_t)blockIdx.x * 2 + 0) * GL_H + f] = v1;
+                a.partials[((int64_t)blockIdx.x * 2 + 1) * GL_H + f] = v2;
+            }
+        }
+    } else {
+        float* slab = a.slabs + (int64_t)blockIdx.x * (GL_H * 32);                  // [256 f][32 k]: element (f = tile * 16 + 4 q4 + e, k = 16 q + s16)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < (PASS == 0 ? 1 : 2); ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) slab[((4 * wave + t) * 16 + 4 * q4 + e) * 32 + 16 * q + s16] = acc[t][q][e];
+    }
+}
+
+// out[p * q_valid + q] = sum over S slabs of slab[p * Q + q], q < q_valid, in a fixed order (reproducible).  dW2: P = 16, Q = q_valid = 256;
+// dW1: P = 256, Q = 32, q_valid = 20.  A block folds 64 outputs: 4 slab lanes x 64 outputs, four loads in flight per thread, then LDS.
+// grid (P * q_valid + 63) / 64 blocks of 256 threads.
+__global__ __launch_bounds__(256) void glove_reduce_kernel(const float* __restrict__ slabs, int S, int P, int Q, int q_valid, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    float acc = 0.f;
+    if (i < P * q_valid) {
+        const int p = i / q_valid, q = i % q_valid;
+        const float* src = slabs + (int64_t)p * Q + q;
+        const int64_t stride = (int64_t)P * Q;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = g;
+        for (; k + 12 < S; k += 16) { a0 += src[(k + 0) * stride]; a1 += src[(k + 4) * stride]; a2 += src[(k + 8) * stride]; a3 += src[(k + 12) * stride]; }
+        for (; k < S; k += 4) a0 += src[k * stride];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    red[g][o] = acc;
+    __syncthreads();
+    if (g == 0 && i < P * q_valid) out[i] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
