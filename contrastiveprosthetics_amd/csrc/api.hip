@@ -855,7 +855,7 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
 }
 
 template <typename T> static int conv_backward_tail(const cp_config*, const cp_params*, const float*, unsigned char*, const WS&, cp_params*, hipStream_t,
-                                                    hipEvent_t, T*, T*, bool, int, const Aux* aux = nullptr);
+                                                    hipEvent_t, T*, T*, bool, int, const Aux* aux = nullptr, int gcol_rows = 0);
 
 template <typename T>
 static int encoder_backward_small_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
@@ -1482,18 +1482,19 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
 // pre-activation) when bn_done, as [N][768] == [(N*12)][64] T; nxt = scratch of the same size
 template <typename T>
 static int conv_backward_tail(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
-                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows, const Aux* aux) {
+                              cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows, const Aux* aux,
+                              int gcol_rows) {
     using D = DT<T>;
     const int64_t N = c->n_windows, R12 = N * 12;
     float* partials = (float*)(base + w.partials);
-    const bool side = aux && aux->on && bn_done;          // conv2's weight gradient on the second stream (its input `cur` is final on entry)
-    float* slabs = (float*)(base + (side ? w.slabs_b : w.slabs));
-    const hipStream_t sw = side ? aux->side : st;
+    // (round 4: conv2's weight gradient is on the critical path again -- BatchNorm1's backward sums follow from it -- so nothing of
+    //  the conv stack floats on the second stream)
+    float* slabs = (float*)(base + w.slabs);
     float* coef = (float*)(base + w.coef);
+    float* rows2 = (float*)(base + w.partials2);
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
-    int conv_dgrad_rows = 0;
-    const PreReduce pre{partials, (float*)(base + w.partials2), st};
+    const PreReduce pre{partials, rows2, st};
     auto bwd_finalize = [&](const float* pp, int nr, double count, int l, int C, int nfold, const char* what) -> int {
         const float* local = nullptr;
         if (c->stats_allreduce) {
@@ -1512,68 +1513,84 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
         if (aux) { if (int e = aux->join()) return e; }          // (the fc weight gradients that ran on the second stream included)
         CK(hipEventRecord(fc_grads_ready, st));
     }
-    if (side) { if (int e = aux->fork()) return e; }
     // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
-    {
-        if (!bn_done) {
-            ProfScope ps(CP_K_BN_BWD, st);
-            int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
-            const float* pp = pre(nr, 2 * 768);
-            if (int e = bwd_finalize(pp, nr, (double)R12, 1, 64, 12, "bn_bwd_finalize_kernel(conv2)")) return e;
-            const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
-            hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
-            nr = gb;
-            pp = pre(nr, 64);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
-            CKL("bn_relu_bwd_kernel(conv2)");
-        }
-        if (int e = tap_gradient(c, 1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
-        ConvArgs ca{};
-        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0); ca.gin = cur; ca.n_windows = N;
-        {
-            ProfScope ps(CP_K_CONV2_WGRAD, sw);
-            const int64_t strips = (N + CONV_WG_WPB - 1) / CONV_WG_WPB;
-            const int64_t cap = sizeof(T) == 2 ? 512 : 256;      // two blocks per CU (194 registers with the strip prefetch)
-            const int S = (int)(strips < cap ? strips : cap);
-            ca.partials = slabs;
-            hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, sw, ca);
-            // up to 512 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
-            // unused tail of the slab buffer), then the scatter kernel walks 32 instead of 512
-            const float* sl = slabs;
-            int ns = S;
-            if (S > 2 * REDUCE_SLICES) {
-                float* folded = slabs + (size_t)S * 64 * 192;
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(64 * 192 / 64, REDUCE_SLICES), dim3(256), 0, sw, slabs, S, 64 * 192, folded);
-                sl = folded;
-                ns = REDUCE_SLICES;
-            }
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(48), dim3(256), 0, sw, sl, ns, 64, 192, 64, (const float*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, g->conv2_w, 2, (float*)nullptr);
-            CKL("conv2_wgrad_kernel");
-        }
-        conv_dgrad_rows = conv_grid<T>(N);
-        ca.wc = base + w.wc2_d; ca.out = nxt; ca.partials = partials;
-        {
-            ProfScope ps(CP_K_CONV2_DGRAD, st);
-            hipLaunchKernelGGL((conv2_strip_kernel<T, 1>), dim3(conv_dgrad_rows), dim3(256), 0, st, ca);
-            CKL("conv2_strip_kernel<dgrad>");
-        }
+    if (!bn_done) {
+        ProfScope ps(CP_K_BN_BWD, st);
+        int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout
+        const float* pp = pre(nr, 2 * 768);
+        if (int e = bwd_finalize(pp, nr, (double)R12, 1, 64, 12, "bn_bwd_finalize_kernel(conv2)")) return e;
+        const int gb = grid_rows(R12, 256 / (64 / D::EPC), 2048);
+        hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(1), coef, partials, R12, 64);
+        nr = gb;
+        pp = pre(nr, 64);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(FIN_GRID(64)), dim3(FIN_THREADS), 0, st, pp, nr, 64, g->conv2_b);
+        CKL("bn_relu_bwd_kernel(conv2)");
+        gcol_rows = 0;
     }
-    if (int e = tap_gradient(c, 0, nxt, N, 768, sizeof(T), st)) return e;             // dL/d(BN1 output), [w][c]
-    // ---- conv1 -----------------------------------------------------------------------------
+    if (int e = tap_gradient(c, 1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
+    // column sums of that gradient per (position, channel): `partials` still holds them as fc1's data-gradient launch wrote them
+    // (gcol_rows rows of 768, its bias-gradient rows); a caller without such rows gets them from one pass over the tensor
+    if (gcol_rows <= 0) {
+        constexpr int cpr = 768 / D::EPC, rpp = 256 / cpr;
+        int64_t gb = (N + rpp - 1) / rpp;
+        if (gb > 256) gb = 256;
+        ProfScope ps(CP_K_BN_BWD, st);
+        hipLaunchKernelGGL((colsum_kernel<T>), dim3((int)gb), dim3(256), (size_t)rpp * 768 * 4, st, cur, partials, N, 768, 768);
+        CKL("colsum_kernel(conv2 gradient)");
+        gcol_rows = (int)gb;
+    }
+    ConvArgs ca{};
+    ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = nullptr; ca.gin = cur; ca.n_windows = N;
+    {
+        // the RAW product g^T r1 (the image holds conv1's rounded ReLU output): BatchNorm1's scale and shift are applied to the
+        // 64 x 192 result, and the same product gives BatchNorm1's backward sums (conv2_wgrad_finish_kernel)
+        ProfScope ps(CP_K_CONV2_WGRAD, st);
+        const int64_t strips = (N + CONV_WG_WPB - 1) / CONV_WG_WPB;
+        const int64_t cap = sizeof(T) == 2 ? 512 : 256;      // two blocks per CU (194 registers with the strip prefetch)
+        const int S = (int)(strips < cap ? strips : cap);
+        ca.partials = slabs;
+        hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
+        CKL("conv2_wgrad_kernel");
+        // up to 512 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
+        // unused tail of the slab buffer), then the finish kernel walks 32 instead of 512
+        const float* sl = slabs;
+        int ns = S;
+        if (S > 2 * REDUCE_SLICES) {
+            float* folded = slabs + (size_t)S * 64 * 192;
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(64 * 192 / 64, REDUCE_SLICES), dim3(256), 0, st, slabs, S, 64 * 192, folded);
+            sl = folded;
+            ns = REDUCE_SLICES;
+        }
+        hipLaunchKernelGGL((conv2_wgrad_finish_kernel<T>), dim3(32), dim3(256), 0, st, sl, ns, partials, gcol_rows, p->conv2_w, stats(0),
+                           g->conv2_w, rows2);
+        CKL("conv2_wgrad_finish_kernel");
+    }
+    {
+        ProfScope ps(CP_K_BN_BWD, st);
+        if (int e = bwd_finalize(rows2, 32, (double)R12, 0, 64, 1, "bn_bwd_finalize_kernel(conv1)")) return e;
+    }
+    const int grid_d = conv_grid<T>(N);
+    ca.wc = base + w.wc2_d; ca.coef = coef;
+    if (c->grad_tap) {
+        // test aid: dL/d(BN1 output) is not a tensor of the step any more; the tap gets it from the stand-alone data-gradient kernel
+        ca.out = nxt; ca.partials = partials;
+        hipLaunchKernelGGL((conv2_strip_kernel<T, 1>), dim3(grid_d), dim3(256), 0, st, ca);
+        CKL("conv2_strip_kernel<dgrad> (gradient tap)");
+        if (int e = tap_gradient(c, 0, nxt, N, 768, sizeof(T), st)) return e;         // dL/d(BN1 output), [w][c]
+    }
+    // ---- conv2's data gradient, BatchNorm1 + ReLU backward and conv1's gradients in one pass over cur ------------------
+    {
+        ProfScope ps(CP_K_CONV2_DGRAD, st);
+        ca.out = nullptr; ca.partials = partials;
+        hipLaunchKernelGGL((conv2_dgrad_conv1_kernel<T>), dim3(grid_d), dim3(256), 0, st, ca);
+        CKL("conv2_dgrad_conv1_kernel");
+    }
     {
         ProfScope ps(CP_K_CONV1_BWD, st);
-        int nr = conv_dgrad_rows;
-        const float* pp = pre(nr, 2 * 64);
-        if (int e = bwd_finalize(pp, nr, (double)R12, 0, 64, 1, "bn_bwd_finalize_kernel(conv1)")) return e;
-        constexpr int RPP = 256 / (64 / D::EPC);                      // windows per block and pass
-        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
-        const int gb = (int)((need + passes - 1) / passes);           // every block makes the same number of passes
-        hipLaunchKernelGGL((conv1_bwd_kernel<T>), dim3(gb), dim3(256), 0, st, nxt, x, p->conv1_w, p->conv1_b, coef, partials, R12);
-        nr = gb;
-        pp = pre(nr, 4 * 64, 2 * REDUCE_SLICES);
+        int nr = grid_d;
+        const float* pp = pre(nr, 4 * 64, 2 * REDUCE_SLICES);
         hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, g->conv1_w, g->conv1_b);
-        CKL("conv1_bwd_kernel");
+        CKL("conv1_bwd_finalize_kernel");
     }
     if (aux) { if (int e = aux->join()) return e; }      // everything the second stream was given is part of this call
     return 0;
@@ -1591,7 +1608,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
     auto act = [&](int l) { return (T*)(base + w.act[l]); };
     auto stats = [&](int l) { return (float*)(base + w.stats[l]); };
     const int tiles_n = (int)((N + fc_bm<T>() - 1) / fc_bm<T>());
-    int conv_dgrad_rows = 0;
+    int gcol_rows = 0;           // partial rows [768] of fc1's data-gradient launch: column sums of dL/d(conv2 pre-activation)
     int stat_rows = tiles_n;     // partial rows holding the BN-backward sums for the next bn_bwd_finalize
     const PreReduce pre{partials, (float*)(base + w.partials2), st};
     // BatchNorm backward, step 1 for layer l (C channels, each seen nfold times in the partial rows): sums -> coefficients of
@@ -1819,6 +1836,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 ProfScope ps(CP_K_FC_DGRAD_BN, st);                        // data gradient + BN/ReLU backward of the layer below
                 CK((launch_fc_gemm<T, EPI_DGRAD>(a, st, &drows, dyn_tiles(c))));
             }
+            if (Lp == 1) gcol_rows = drows;                               // (the conv tail reads these bias-gradient rows once more)
             {
                 ProfScope ps(CP_K_BN_BWD, st);
                 int nr = drows * nfold;                                   // rows of K = nfold rows of Cp
@@ -1844,7 +1862,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             T* tmp = cur; cur = nxt; nxt = tmp;
         }
     }
-    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, cur, nxt, bn_done, stat_rows, &aux);
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, cur, nxt, bn_done, stat_rows, &aux, gcol_rows);
 }
 
 
@@ -1900,9 +1918,9 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
     T* dz = (T*)(base + w.dz);
     uint8_t* cur = base + w.g8[0];
     uint8_t* nxt = base + w.g8[1];
-    int stat_rows = 0;
+    int stat_rows = 0, gcol_rows = 0;
     bool bn_done = false;
-    // second stream (encoder_backward_t): the projection's, fc7's + fc6's, fc5's and conv2's weight gradients float beside the critical path
+    // second stream (encoder_backward_t): the projection's, fc7's + fc6's and fc5's weight gradients float beside the critical path
     const Aux aux = make_aux(c, st, drop);
     float* slabs_b = (float*)(base + w.slabs_b);
     if (aux.on) { cur = base + w.gkeep[0]; nxt = base + w.gkeep[1]; }
@@ -2045,7 +2063,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             int drows = 0;
             {
                 ProfScope ps(Lp == 1 ? CP_K_FC_DGRAD_CONV : CP_K_FC_DGRAD_BN, st);
-                if (Lp == 1) { a.C = gconv; a.t_out = -1; CK((launch_gemm_wsd8<0, true>(a, st, &drows))); }
+                if (Lp == 1) { a.C = gconv; a.t_out = -1; CK((launch_gemm_wsd8<0, true>(a, st, &drows))); gcol_rows = drows; }
                 else { a.C = nxt; a.t_out = F8_T_GRAD + Lp; CK((launch_gemm_wsd8<0, false>(a, st, &drows))); }
             }
             {
@@ -2073,7 +2091,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             uint8_t* tmp = cur; cur = nxt; nxt = tmp;
         }
     }
-    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gconv, (T*)(base + w.gbuf[1]), true, 0, &aux);
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gconv, (T*)(base + w.gbuf[1]), true, 0, &aux, gcol_rows);
 }
 
 extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,

@@ -25,6 +25,7 @@ struct ConvArgs {
     const void* wc;         // conv2 weights in compute dtype [64][192] (k = tap*64 + in-channel)
     const float* bias2;     // conv_emg.3.bias (forward)
     const void* gin;        // [N*12][64] T gradient wrt conv2's pre-BN output (dgrad / wgrad)
+    const float* coef;      // conv2_dgrad_conv1_kernel: BatchNorm1-backward coefficients [3][64] (bn_bwd_finalize_kernel)
     void* out;              // forward: r2, dgrad: g_v1   [N*12][64] T
     uint8_t* out8;          // forward, CP_FP8: r2 as e4m3 [N*12][64] INSTEAD of `out`, scale 2^*out_exp, running maximum in *out_amax
     const int* out_exp;
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) wt[e][k] = a.w1[c * 9 + 3 + k];
         bs[e] = a.b1[c];
-        sc[e] = a.stats1[2 * 64 + c];
-        sh[e] = a.stats1[3 * 64 + c];
+        sc[e] = a.stats1 ? a.stats1[2 * 64 + c] : 1.f;         // nullptr: the image holds the raw r1 (conv2_wgrad_finish_kernel
+        sh[e] = a.stats1 ? a.stats1[3 * 64 + c] : 0.f;         // applies BatchNorm1's scale and shift to the 64 x 192 product)
     }
     f32x16 acc[3];
 #pragma unroll
@@ -490,8 +491,10 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
                 const int wpos = ok ? wp - 1 : 0;
                 float t[EPC];
                 conv1_chunk_vals<T>(wpos > 0 ? xr[q][0] : 0.f, xr[q][1], wpos < 11 ? xr[q][2] : 0.f, wt, bs, t);
+                if (a.stats1 != nullptr) {
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
+                    for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
+                }
                 uint4 yv = D::pack(t);
                 uint4 xv = xg[q];
                 if (!ok) { xv = make_uint4(0, 0, 0, 0); yv = make_uint4(0, 0, 0, 0); }
@@ -529,6 +532,159 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
             const int p = ot * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
             slab[p * 192 + q] = acc[tap][g];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv2 data gradient + BatchNorm1 / ReLU backward + conv1's weight and bias gradient in ONE pass over g_y2 (round 4).
+// dL/d(BN1 output) = g_v1 is never written: the BatchNorm1-backward coefficients exist before the launch (their two sums
+// follow from conv2's weight gradient: conv2_wgrad_finish_kernel), so each 32 x 32 accumulator tile is consumed where it
+// lands.  The tile is formed TRANSPOSED against conv2_strip_kernel (image rows as the MFMA's A operand, weights as B): a lane
+// holds ONE conv1 channel (its three taps, bias and three coefficients: 7 registers) and 16 rows, in groups of four
+// consecutive positions of one window; the six inputs under such a group's taps come from a zero-padded copy of the strip's
+// x in LDS (16 floats per window: one 16-byte and one 8-byte read).  Per element:
+//     r1 = round_T(relu(b + w . x))          (conv1_chunk_vals' order of operations: the value every other consumer sees)
+//     gy = r1 > 0 ? ca g_v1 + cb r1 + cz : 0
+//     dW1[c][tap] += gy x[pos + tap - 1],  db1[c] += gy
+// partials[block][4][64]: dW tap 0..2, db (conv1_bwd_finalize_kernel).  Two barriers per strip (image published, image dead);
+// no output tile in LDS.  Replaces conv2_strip_kernel<T, 1> + conv1_bwd_kernel: 258 MB less written and 266 MB less read per
+// step at 167,936 windows.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv2_dgrad_conv1_kernel(ConvArgs a) {
+    using D = DT<T>;
+    using G = ConvGeo<T>;
+    constexpr int EPC = G::EPC, CPR = G::CPR, ROWB = G::ROWB, RPP = G::RPP, WPITCH = G::WPITCH;
+    constexpr int KSTEP = D::KSTEP, KS_PER_TAP = 64 / KSTEP, NKS = 3 * KS_PER_TAP;
+    constexpr int IMG_BYTES = CONV_IMG_ROWS * ROWB, W_BYTES = 64 * WPITCH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IMG_BYTES + W_BYTES];
+    __shared__ __attribute__((aligned(16))) float xpad[2][CONV_WPB * 16];      // [window][0, x0..x11, 0, -, -], double-buffered
+    static_assert(IMG_BYTES >= 4 * 8 * 32 * 4, "the end-of-kernel reduction reuses the image region");
+    unsigned char* img = smem;
+    unsigned char* Wl = smem + IMG_BYTES;
+    float* red = (float*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int cc = tid % CPR, rr = tid / CPR;
+    const int ft = wave & 1, st0 = 3 * (wave >> 1);
+    const int64_t nstrips = (a.n_windows + CONV_WPB - 1) / CONV_WPB;
+    const int64_t total_rows = a.n_windows * 12;
+
+    for (int i = tid; i < 64 * (192 / EPC); i += 256) {
+        const int row = i / (192 / EPC), ch = i % (192 / EPC);
+        *(uint4*)(Wl + row * WPITCH + ch * 16) = *(const uint4*)((const T*)a.wc + row * 192 + ch * EPC);
+    }
+    for (int i = tid; i < 2 * CONV_WPB * 16; i += 256) (&xpad[0][0])[i] = 0.f;
+    // this lane's conv1 channel
+    const int ch1 = ft * 32 + r;
+    const float w0 = a.w1[ch1 * 9 + 3], w1 = a.w1[ch1 * 9 + 4], w2 = a.w1[ch1 * 9 + 5], b1 = a.b1[ch1];
+    const float ca = a.coef[ch1], cb = a.coef[64 + ch1], cz = a.coef[128 + ch1];
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+
+    auto load_x = [&](int64_t strip) {
+        const int64_t i = strip * (CONV_WPB * 12) + tid;
+        return (tid < CONV_WPB * 12 && strip < nstrips && i < total_rows) ? a.x[i] : 0.f;
+    };
+    const int xslot = (tid / 12) * 16 + 1 + tid % 12;          // (tid < 192)
+    constexpr int NITG = CONV_IMG_ROWS / RPP;
+    uint4 pg[NITG];
+    auto prefetch_g = [&](int64_t strip) {
+#pragma unroll
+        for (int it = 0; it < NITG; ++it) {
+            const int ir = rr + it * RPP;
+            const int nl = ir / 14, wp = ir % 14;
+            const int64_t win = strip * CONV_WPB + nl;
+            const bool ok = strip < nstrips && wp >= 1 && wp <= 12 && win < a.n_windows;
+            pg[it] = *(const uint4*)((const T*)a.gin + ((ok ? win : 0) * 12 + (ok ? wp - 1 : 0)) * 64 + cc * EPC);
+            if (!ok) pg[it] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    __syncthreads();                                   // (the zeroed pads before the first x values)
+    if (tid < CONV_WPB * 12) xpad[0][xslot] = load_x(blockIdx.x);
+    prefetch_g(blockIdx.x);
+    int xb = 0;
+    int ir0[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int ml = (st0 + j) * 32 + r;
+        ir0[j] = (ml / 12) * 14 + (ml % 12);
+    }
+    for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int64_t win0 = strip * CONV_WPB;
+        const float x_next = load_x(strip + gridDim.x);
+#pragma unroll
+        for (int it = 0; it < NITG; ++it) *(uint4*)(img + G::img_off(rr + it * RPP, cc)) = pg[it];
+        __syncthreads();
+        prefetch_g(strip + gridDim.x);
+        f32x16 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int tap = ks / KS_PER_TAP, chunk = (ks % KS_PER_TAP) * 2 + h;
+            const uint4 fw = *(const uint4*)(Wl + (ft * 32 + r) * WPITCH + ks * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint4 fs = *(const uint4*)(img + G::img_off(ir0[j] + tap, chunk));
+                mma_chunk<T>(fs, fw, acc[j]);          // D[row = sample][col = channel]
+            }
+        }
+        if (tid < CONV_WPB * 12) xpad[xb ^ 1][xslot] = x_next;          // read from the next strip on, two barriers away
+        __syncthreads();                               // image dead: the next strip may be staged
+        const float* xs = xpad[xb];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mb = (st0 + j) * 32 + 8 * q + 4 * h;           // four consecutive rows of one window
+                const int nl = mb / 12, p0 = mb % 12;
+                const bool valid = win0 + nl < a.n_windows;
+                const float4 xa = *(const float4*)(xs + nl * 16 + p0);
+                const float2 xc = *(const float2*)(xs + nl * 16 + p0 + 4);
+                const float X[6] = {xa.x, xa.y, xa.z, xa.w, xc.x, xc.y};
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    float y0 = fmaf(w2, X[e + 2], fmaf(w1, X[e + 1], fmaf(w0, X[e], b1)));
+                    float y1 = fmaf(w2, X[e + 3], fmaf(w1, X[e + 2], fmaf(w0, X[e + 1], b1)));
+                    float r0, r1;
+                    if constexpr (sizeof(T) == 2) {
+                        const uint32_t pk = cvt_pk_bf16<true>(y0, y1);
+                        r0 = __uint_as_float(pk << 16);
+                        r1 = __uint_as_float(pk & 0xffff0000u);
+                    } else {
+                        r0 = fmaxf(y0, 0.f);
+                        r1 = fmaxf(y1, 0.f);
+                    }
+                    const float t0 = fmaf(ca, acc[j][4 * q + e], fmaf(cb, r0, cz));
+                    const float t1 = fmaf(ca, acc[j][4 * q + e + 1], fmaf(cb, r1, cz));
+                    const float g0 = (r0 > 0.f && valid) ? t0 : 0.f;
+                    const float g1 = (r1 > 0.f && valid) ? t1 : 0.f;
+                    d0 = fmaf(g0, X[e], d0);     d1 = fmaf(g0, X[e + 1], d1); d2 = fmaf(g0, X[e + 2], d2); d3 += g0;
+                    d0 = fmaf(g1, X[e + 1], d0); d1 = fmaf(g1, X[e + 2], d1); d2 = fmaf(g1, X[e + 3], d2); d3 += g1;
+                }
+                __builtin_amdgcn_sched_barrier(0);     // (one group's six inputs live at a time: hoisted together they spill)
+            }
+        }
+        xb ^= 1;
+    }
+    __syncthreads();
+    // red[k][wave * 2 + h][r]: the four (wave pair, h) parts of each channel
+    red[(0 * 8 + wave * 2 + h) * 32 + r] = d0;
+    red[(1 * 8 + wave * 2 + h) * 32 + r] = d1;
+    red[(2 * 8 + wave * 2 + h) * 32 + r] = d2;
+    red[(3 * 8 + wave * 2 + h) * 32 + r] = d3;
+    __syncthreads();
+    {
+        const int k = tid >> 6, c = tid & 63, f = c >> 5, cl = c & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int wq = 0; wq < 2; ++wq)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) s += red[(k * 8 + (f + 2 * wq) * 2 + hh) * 32 + cl];
+        a.partials[((int64_t)blockIdx.x * 4 + k) * 64 + c] = s;
     }
 }
 

@@ -423,14 +423,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     float sum[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) sum[e] = 0.f;
-    for (int64_t m = (int64_t)blockIdx.x * rpp + rr; m < rows; m += (int64_t)gridDim.x * rpp) {
+    // (C = 768: 96 or 192 chunks per row do not divide 256 -- the threads past the last whole row idle)
+    for (int64_t m = (int64_t)blockIdx.x * rpp + rr; rr < rpp && m < rows; m += (int64_t)gridDim.x * rpp) {
         float v[EPC];
         D::unpack(*(const uint4*)(x + m * ld + cc * EPC), v);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) sum[e] += v[e];
     }
+    if (rr < rpp) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) dyn_red[rr * C + cc * EPC + e] = sum[e];
+        for (int e = 0; e < EPC; ++e) dyn_red[rr * C + cc * EPC + e] = sum[e];
+    }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float s = 0.f;
@@ -546,6 +549,79 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
             if (s != nullptr) acc = fmaf(s[ch], acc, t[ch] * dbsum[p]);
             grad[dst] = acc;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// conv2's weight gradient finished, and BatchNorm1's backward sums with it (round 4): no N-sized tensor is read.
+// conv2_wgrad_kernel left slabs of the RAW product  P[o][tap][c] = sum_{n,q} g[n][q][o] r1[n][q + tap - 1][c]  (r1 = conv1's
+// rounded ReLU output, zero outside the 12 positions).  With u1 = s r1 + t (BatchNorm1, zero-padded AFTER the affine map) and
+// G[o][tap] = sum of g[n][q][o] over the positions q whose tap lands inside the window (tap 0: q >= 1, tap 2: q <= 10):
+//     dW2[o][c][tap] = s[c] P + t[c] G[o][tap]
+//     S1[c] = sum_{n,p} g_v1[n][p][c]           = sum_{o,tap} W2[o][c][tap] G[o][tap]
+//     S2[c] = sum_{n,p} g_v1[n][p][c] r1[n][p][c] = sum_{o,tap} W2[o][c][tap] P[o][tap][c]
+// (g_v1 = conv2's data gradient; W2 rounded as the data-gradient kernel's operand is).  gcols: nr partial rows [768] of the column
+// sums of g seen as [N][q * 64 + o] -- the bias-gradient rows fc1's data-gradient launch wrote, or colsum_kernel's.
+// grid 32 blocks (two output channels each) x 256 threads; out_rows[32][2][64] in bn_bwd_finalize_kernel's layout.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv2_wgrad_finish_kernel(const float* __restrict__ slabs, int S, const float* __restrict__ gcols, int nr,
+                                                                 const float* __restrict__ W2, const float* __restrict__ stats1,
+                                                                 float* __restrict__ dW2, float* __restrict__ out_rows) {
+    using D = DT<T>;
+    __shared__ double part[10][24];
+    __shared__ float Gs[2][3];
+    __shared__ float red[2][6][64];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid < 240) {
+        const int pi = tid % 24, ls = tid / 24, ol = pi / 12, q = pi % 12;
+        double s = 0;
+        for (int rw = ls; rw < nr; rw += 10) s += (double)gcols[(int64_t)rw * 768 + q * 64 + 2 * b + ol];
+        part[ls][pi] = s;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double cs[12], all = 0;
+        for (int q = 0; q < 12; ++q) {
+            double s = 0;
+            for (int ls = 0; ls < 10; ++ls) s += part[ls][tid * 12 + q];
+            cs[q] = s;
+            all += s;
+        }
+        Gs[tid][0] = (float)(all - cs[0]);
+        Gs[tid][1] = (float)all;
+        Gs[tid][2] = (float)(all - cs[11]);
+    }
+    __syncthreads();
+    for (int e = tid; e < 384; e += 256) {
+        const int ol = e / 192, q = e % 192, tap = q >> 6, c = q & 63, o = 2 * b + ol;
+        const float* src = slabs + o * 192 + q;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= S; k += 4) {
+            a0 += src[(int64_t)(k + 0) * 64 * 192];
+            a1 += src[(int64_t)(k + 1) * 64 * 192];
+            a2 += src[(int64_t)(k + 2) * 64 * 192];
+            a3 += src[(int64_t)(k + 3) * 64 * 192];
+        }
+        for (; k < S; ++k) a0 += src[(int64_t)k * 64 * 192];
+        const float P = (a0 + a1) + (a2 + a3);
+        const float G = Gs[ol][tap];
+        const int base = (o * 64 + c) * 9;
+        dW2[base + 3 + tap] = fmaf(stats1[2 * 64 + c], P, stats1[3 * 64 + c] * G);
+        dW2[base + 0 + tap] = 0.f;
+        dW2[base + 6 + tap] = 0.f;
+        const float w = D::round(W2[base + 3 + tap]);
+        red[0][ol * 3 + tap][c] = w * G;
+        red[1][ol * 3 + tap][c] = w * P;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += red[which][k][c];
+        out_rows[((int64_t)b * 2 + which) * 64 + c] = s;
     }
 }
 

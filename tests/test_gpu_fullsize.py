@@ -415,13 +415,17 @@ def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
     assert float(G["emg_net.conv_emg.3.weight"][:, :, 0, :].abs().max()) == 0.0      # rows 0 and 2 only ever meet padding
     assert float(G["emg_net.conv_emg.3.weight"][:, :, 2, :].abs().max()) == 0.0
     gu1 = sum(_shift_w(g2, 1 - t) @ wc2[:, :, t] for t in range(3))
-    check_tensor("bwd/conv2_dgrad (conv2_strip<1>)", tap[0].reshape(N, 12, 64), gu1)
-    # conv1: BN1 + ReLU backward fused with conv1's dW / db, from the kernel's own input tap[0]
-    gu1 = tap[0].reshape(N * 12, 64).float()
+    check_tensor("bwd/conv2_dgrad (conv2_strip<1>, the tap's stand-alone launch)", tap[0].reshape(N, 12, 64), gu1)
+    # conv1: BN1 + ReLU backward fused with conv2's data gradient and conv1's dW / db (conv2_dgrad_conv1_kernel, round 4): that
+    # gradient is never stored, so the reference is the fp32 product of the kernel's inputs -- tap[1] and the weights as its
+    # operand holds them (bf16-rounded) -- not the tap's bf16 copy; BatchNorm1's sums come from conv2's raw weight-gradient
+    # product (conv2_wgrad_finish_kernel), i.e. f32 sums of exact bf16 x bf16 products
+    wc2r = wc2.to(torch.bfloat16).float() if dtype != "f32" else wc2
+    gu1 = sum(_shift_w(g2, 1 - t) @ wc2r[:, :, t] for t in range(3)).reshape(N * 12, 64)
     g0, dg, db_ = _bn_backward(gu1, r0.reshape(N * 12, 64), st[0][0], st[0][1], W[bnn[0] + ".weight"], N * 12)
     g0 = (g0 * (r0.reshape(N * 12, 64) > 0)).reshape(N, 12, 64)
-    check_param("bwd/bn0_gamma", G[bnn[0] + ".weight"], dg, tol=1e-5)
-    check_param("bwd/bn0_beta", G[bnn[0] + ".bias"], db_, tol=1e-5)
+    check_param("bwd/bn0_gamma (from conv2's weight-gradient product)", G[bnn[0] + ".weight"], dg, tol=2e-4)
+    check_param("bwd/bn0_beta (from the column sums of tap[1])", G[bnn[0] + ".bias"], db_, tol=2e-4)
     check_param("bwd/conv1_b", G["emg_net.conv_emg.0.bias"], g0.reshape(-1, 64).sum(0))
     dw1 = torch.stack([(g0 * xp[:, t:t + 12].unsqueeze(-1)).reshape(-1, 64).sum(0) for t in range(3)], -1)   # (64, 3)
     check_param("bwd/conv1_w", G["emg_net.conv_emg.0.weight"][:, 0, 1, :], dw1)
