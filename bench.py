@@ -598,10 +598,9 @@ def main():
                     hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
                     gemm_ms_per_step={k: prof[k][0] / profiled_steps for k in gemm_kinds if k in prof},
                     second_stream=bool(aux_default and eng._aux is not None),
-                    note="per-kernel durations: HIP events around each launch on the profiled steps, which run on ONE stream (kernel alone on the chip); "
-                         "the other timed steps float the off-critical-path weight gradients on cp_config.aux_stream, where a launch's wall time "
-                         "includes what it shares the chip with (profiles/r04_kernel_stats.csv = the default command, r04_serial_kernel_stats.csv = "
-                         "CPNATIVE_AUX_STREAM=0: the durations these figures agree with)",
+                    note="per-kernel durations: HIP events around each launch on the profiled steps, which run on ONE stream, as the timed steps do "
+                         "by default (second_stream false; with CPNATIVE_AUX_STREAM=1 the timed steps float the weight gradients behind a dropout on "
+                         "cp_config.aux_stream and a launch's wall time includes what it shares the chip with)",
                     profiled_steps=profiled_steps,
                     per_kernel=per_kernel)
         # the step as a whole against SURVEY 8d's byte model (51.3 KB per window in 16-bit storage, 102.5 in f32, 25.6 in 8-bit)

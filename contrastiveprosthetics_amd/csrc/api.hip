@@ -855,7 +855,8 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
 }
 
 template <typename T> static int conv_backward_tail(const cp_config*, const cp_params*, const float*, unsigned char*, const WS&, cp_params*, hipStream_t,
-                                                    hipEvent_t, T*, T*, bool, int, const Aux* aux = nullptr, int gcol_rows = 0);
+                                                    hipEvent_t, T*, T*, bool, int, const Aux* aux = nullptr, int gcol_rows = 0,
+                                                    const Fp8State* g8 = nullptr);
 
 template <typename T>
 static int encoder_backward_small_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
@@ -1483,7 +1484,9 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
 template <typename T>
 static int conv_backward_tail(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
                               cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows, const Aux* aux,
-                              int gcol_rows) {
+                              int gcol_rows, const Fp8State* g8) {
+    // g8 (CP_FP8): `cur` holds e5m2 bytes with the scale of tensor F8_T_GRAD + 1 (fc1's data-gradient launch wrote them), expanded into
+    // the kernels' bf16 images while they are staged; the bias-gradient rows (gcol_rows) are in true units
     using D = DT<T>;
     const int64_t N = c->n_windows, R12 = N * 12;
     float* partials = (float*)(base + w.partials);
@@ -1527,7 +1530,17 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
         CKL("bn_relu_bwd_kernel(conv2)");
         gcol_rows = 0;
     }
-    if (int e = tap_gradient(c, 1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
+    const int* gexp = g8 ? (const int*)&g8->e[F8_T_GRAD + 1] : nullptr;
+    if (g8) {
+        if (gcol_rows <= 0 || sizeof(T) != 2) return fail(CP_ERR_ARG, "conv_backward_tail: 8-bit gradient without its column sums");
+        if (c->grad_tap) {
+            const size_t slot_bytes = (size_t)N * 768 * 2;
+            if (2 * slot_bytes > c->grad_tap_bytes) return fail(CP_ERR_ARG, "gradient tap buffer too small");
+            hipLaunchKernelGGL(dequant5_bf16_kernel, dim3(1024), dim3(256), 0, st, (const uint8_t*)cur, (bf16_t*)((unsigned char*)c->grad_tap + slot_bytes),
+                               N * 192, g8, F8_T_GRAD + 1);
+            CKL("dequant5_bf16_kernel(conv2 gradient)");
+        }
+    } else if (int e = tap_gradient(c, 1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation), [w][c]
     // column sums of that gradient per (position, channel): `partials` still holds them as fc1's data-gradient launch wrote them
     // (gcol_rows rows of 768, its bias-gradient rows); a caller without such rows gets them from one pass over the tensor
     if (gcol_rows <= 0) {
@@ -1540,7 +1553,7 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
         gcol_rows = (int)gb;
     }
     ConvArgs ca{};
-    ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = nullptr; ca.gin = cur; ca.n_windows = N;
+    ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = nullptr; ca.gin = cur; ca.gin_exp = gexp; ca.n_windows = N;
     {
         // the RAW product g^T r1 (the image holds conv1's rounded ReLU output): BatchNorm1's scale and shift are applied to the
         // 64 x 192 result, and the same product gives BatchNorm1's backward sums (conv2_wgrad_finish_kernel)
@@ -1549,7 +1562,12 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
         const int64_t cap = sizeof(T) == 2 ? 512 : 256;      // two blocks per CU (194 registers with the strip prefetch)
         const int S = (int)(strips < cap ? strips : cap);
         ca.partials = slabs;
-        hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
+        if constexpr (sizeof(T) == 2) {
+            if (g8) hipLaunchKernelGGL((conv2_wgrad_kernel<T, true>), dim3(S), dim3(256), 0, st, ca);
+            else hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
+        } else {
+            hipLaunchKernelGGL((conv2_wgrad_kernel<T>), dim3(S), dim3(256), 0, st, ca);
+        }
         CKL("conv2_wgrad_kernel");
         // up to 512 slabs of 64x192: fold them into REDUCE_SLICES slabs in parallel first (scratch = the
         // unused tail of the slab buffer), then the finish kernel walks 32 instead of 512
@@ -1574,7 +1592,9 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
     if (c->grad_tap) {
         // test aid: dL/d(BN1 output) is not a tensor of the step any more; the tap gets it from the stand-alone data-gradient kernel
         ca.out = nxt; ca.partials = partials;
+        if (g8) ca.gin = (unsigned char*)c->grad_tap + (size_t)N * 768 * 2;          // (its bf16 expansion in tap slot 1)
         hipLaunchKernelGGL((conv2_strip_kernel<T, 1>), dim3(grid_d), dim3(256), 0, st, ca);
+        ca.gin = cur;
         CKL("conv2_strip_kernel<dgrad> (gradient tap)");
         if (int e = tap_gradient(c, 0, nxt, N, 768, sizeof(T), st)) return e;         // dL/d(BN1 output), [w][c]
     }
@@ -1582,7 +1602,12 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
     {
         ProfScope ps(CP_K_CONV2_DGRAD, st);
         ca.out = nullptr; ca.partials = partials;
-        hipLaunchKernelGGL((conv2_dgrad_conv1_kernel<T>), dim3(grid_d), dim3(256), 0, st, ca);
+        if constexpr (sizeof(T) == 2) {
+            if (g8) hipLaunchKernelGGL((conv2_dgrad_conv1_kernel<T, true>), dim3(grid_d), dim3(256), 0, st, ca);
+            else hipLaunchKernelGGL((conv2_dgrad_conv1_kernel<T>), dim3(grid_d), dim3(256), 0, st, ca);
+        } else {
+            hipLaunchKernelGGL((conv2_dgrad_conv1_kernel<T>), dim3(grid_d), dim3(256), 0, st, ca);
+        }
         CKL("conv2_dgrad_conv1_kernel");
     }
     {
@@ -1663,10 +1688,25 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         split_rows(N, 128, &S, &ta.rows_per_split);
 #ifdef CP_VARIANTS
         const bool fused_u8 = drop && !g_var.materialize_u8;
+        const bool proj_alg = fuse_ok && drop && sizeof(T) == 2 && !g_var.materialize_u8 && !g_var.no_proj_fused;
 #else
         const bool fused_u8 = drop;
+        const bool proj_alg = fuse_ok && drop && sizeof(T) == 2;
 #endif
-        if (fused_u8) {
+        if (proj_alg) {
+            // behind fc7's dropout, 16-bit storage (round 4): the weight gradient's launch reads r8 ONCE and leaves both dW and fc7's
+            // BatchNorm-backward sums (gemm_tn.cuh, proj_wgrad_sums_kernel); on the critical path -- the data gradient below needs the sums
+            if constexpr (sizeof(T) == 2) {
+                ProjWgradArgs pa{};
+                pa.dz = (const bf16_t*)dz; pa.R = act(8); pa.slabs = slabs; pa.M = N; pa.rows_per_split = ta.rows_per_split;
+                pa.dp_thresh = dp_thresh(c->dp_emg); pa.dp_key = dp_key(c, 8); pa.dp_salt = dp_salt(c);
+                hipLaunchKernelGGL(proj_wgrad_sums_kernel<false>, dim3(4, S), dim3(256), 0, st, pa);
+                CKL("proj_wgrad_sums_kernel");
+                hipLaunchKernelGGL(proj_wgrad_finish_kernel, dim3(32), dim3(256), 0, st, slabs, S, stats(8) + 2 * 512, stats(8) + 3 * 512, p->last_w,
+                                   dp_inv_keep(c->dp_emg), (const int*)nullptr, g->last_w, partials);
+                CKL("proj_wgrad_finish_kernel");
+            }
+        } else if (fused_u8) {
             // u8 = dropout(BN(fc7)) was never written (encoder_forward_t): formed from the saved activation while staging
             ta.Y = act(8); ta.y_scale = stats(8) + 2 * 512; ta.y_shift = stats(8) + 3 * 512;
             ta.dp_thresh = dp_thresh(c->dp_emg); ta.dp_key = dp_key(c, 8); ta.dp_inv_keep = dp_inv_keep(c->dp_emg); ta.dp_salt = dp_salt(c);
@@ -1675,9 +1715,11 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, sw)));
         }
         float* praw = (float*)(base + w.praw);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
-                           drop ? (float*)nullptr : praw);
-        CKL("reduce_slabs(last)");
+        if (!proj_alg) {
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
+                               drop ? (float*)nullptr : praw);
+            CKL("reduce_slabs(last)");
+        }
         if (!drop) {
             // BN-backward sums of fc7's BN from the projection's weight gradient (no N-sized read)
             hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials,
@@ -1708,12 +1750,16 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
 #else
         } else if (fuse_ok && drop && sizeof(T) == 2) {
 #endif
-            // behind fc7's dropout: the rank-16 product is computed twice (gemm_ws.cuh, proj_dgrad_kernel) -- once for the
-            // BatchNorm-backward sums, once more with fc7's BN + ReLU backward applied -- instead of being written out for a
-            // separate bn_relu_bwd pass
-            CK(launch_proj_dgrad<0>(a, st, &drows));
-            int nr = drows;
-            const float* pp = pre(nr, 2 * 512);
+            // behind fc7's dropout: the rank-16 product is formed with fc7's BN + ReLU backward applied (gemm_ws.cuh, proj_dgrad_kernel<1>)
+            // instead of being written out for a separate bn_relu_bwd pass; the BatchNorm-backward sums it needs came with the weight
+            // gradient above (round 3 and the tools build: a first pass of the same product, proj_dgrad_kernel<0>)
+            int nr = 1;
+            const float* pp = partials;
+            if (!proj_alg) {
+                CK(launch_proj_dgrad<0>(a, st, &drows));
+                nr = drows;
+                pp = pre(nr, 2 * 512);
+            }
             if (int e = bwd_finalize(pp, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
             a.coef = coef; a.coef_mod = 512;
             CK(launch_proj_dgrad<1>(a, st, &drows));
@@ -1866,17 +1912,6 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
 }
 
 
-// e5m2 tensor -> bf16 in true units (the gradient tap of the tests)
-__global__ __launch_bounds__(256) void dequant5_bf16_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int64_t n4,
-                                                            const Fp8State* __restrict__ st, int t) {
-    const float d = f8_exp2i(-st->e[t]);
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float v[4];
-        f8_unpack4_e5m2(*(const uint32_t*)(in + i * 4), v);
-        *(uint2*)(out + i * 4) = make_uint2(pack2bf(v[0] * d, v[1] * d), pack2bf(v[2] * d, v[3] * d));
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // encoder backward, CP_FP8: the fc stack in 8 bits (csrc/fp8.cuh) -- e5m2 gradients between the layers, the saved e4m3
 // activations, W^T as e4m3 -- then the conv stack on the bf16 kernels (fc1's data-gradient launch writes bf16).
@@ -1946,25 +1981,28 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         int S;
         split_rows(N, 128, &S, &ta.rows_per_split);
         if (drop) {
-            ta.y_scale = stats(8) + 2 * 512; ta.y_shift = stats(8) + 3 * 512;
-            ta.dp_thresh = dp_thresh(c->dp_emg); ta.dp_key = dp_key(c, 8); ta.dp_inv_keep = dp_inv_keep(c->dp_emg); ta.dp_salt = dp_salt(c);
-            CK((launch_gemm_tn<T, 64, 128, YLOAD_BNDROP_F8>(ta, S, sw)));
+            // (encoder_backward_t: one pass over r8 for the weight gradient AND fc7's BatchNorm-backward sums, on the critical path)
+            ProjWgradArgs pa{};
+            pa.dz = (const bf16_t*)dz; pa.R = base + w.act8[8]; pa.slabs = slabs; pa.M = N; pa.rows_per_split = ta.rows_per_split;
+            pa.dp_thresh = dp_thresh(c->dp_emg); pa.dp_key = dp_key(c, 8); pa.dp_salt = dp_salt(c);
+            hipLaunchKernelGGL(proj_wgrad_sums_kernel<true>, dim3(4, S), dim3(256), 0, st, pa);
+            CKL("proj_wgrad_sums_kernel<e4m3>");
+            hipLaunchKernelGGL(proj_wgrad_finish_kernel, dim3(32), dim3(256), 0, st, slabs, S, stats(8) + 2 * 512, stats(8) + 3 * 512, p->last_w,
+                               dp_inv_keep(c->dp_emg), (const int*)&fs->e[F8_T_ACT + 8], g->last_w, partials);
+            CKL("proj_wgrad_finish_kernel");
         } else {
             CK((launch_gemm_tn<T, 64, 128, YLOAD_F8>(ta, S, sw)));
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0, praw,
+                               (const int*)nullptr, (const int*)nullptr);
+            CKL("reduce_slabs(last)");
         }
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
-                           drop ? (float*)nullptr : praw, (const int*)nullptr, (const int*)nullptr);
-        CKL("reduce_slabs(last)");
         Proj8Args a{};
         a.A = dz; a.lda = 64; a.W = (const bf16_t*)(base + w.wlast_t); a.K = 64; a.R = base + w.act8[8]; a.C = cur;
         a.partials = partials; a.st = fs; a.t_r = F8_T_ACT + 8; a.t_out = F8_T_GRAD + 8; a.M = N;
         int drows = 0;
         if (drop) {
             a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c);
-            CK(launch_proj_dgrad8<0>(a, st, &drows));
-            int nr = drows;
-            const float* pp = pre(nr, 2 * 512);
-            if (int e = bwd_finalize(pp, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
+            if (int e = bwd_finalize(partials, 1, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
         } else {
             // no dropout behind fc7: its BatchNorm-backward sums follow from the projection's weight gradient (no N-sized read)
             hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials, CP_D_E, 512, 0);
@@ -1982,7 +2020,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
     // ---- fc7 .. fc1 --------------------------------------------------------------------
     struct { const uint8_t* X; const uint8_t* Y; int i, tx, ty; } pend{};
     bool pending = false;
-    T* gconv = (T*)(base + w.gbuf[0]);                       // fc1's data gradient, bf16 [N][768]: what the conv kernels read
+    T* gconv = (T*)(base + w.gbuf[0]);                       // fc1's data gradient, e5m2 [N][768] (F8_T_GRAD + 1): what the conv kernels read
     for (int L = 8; L >= 2; --L) {
         const int i = L - 2, Lp = L - 1, K = fcK(i);
         if (!bn_done) {
@@ -2063,8 +2101,10 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             int drows = 0;
             {
                 ProfScope ps(Lp == 1 ? CP_K_FC_DGRAD_CONV : CP_K_FC_DGRAD_BN, st);
-                if (Lp == 1) { a.C = gconv; a.t_out = -1; CK((launch_gemm_wsd8<0, true>(a, st, &drows))); gcol_rows = drows; }
-                else { a.C = nxt; a.t_out = F8_T_GRAD + Lp; CK((launch_gemm_wsd8<0, false>(a, st, &drows))); }
+                // (fc1's launch writes e5m2 like the others -- round 3's wrote 258 MB of bf16 for the conv kernels; they expand the bytes now)
+                a.C = Lp == 1 ? (void*)gconv : (void*)nxt; a.t_out = F8_T_GRAD + Lp;
+                CK((launch_gemm_wsd8<0, false>(a, st, &drows)));
+                if (Lp == 1) gcol_rows = drows;
             }
             {
                 ProfScope ps(CP_K_BN_BWD, st);
@@ -2091,7 +2131,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             uint8_t* tmp = cur; cur = nxt; nxt = tmp;
         }
     }
-    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gconv, (T*)(base + w.gbuf[1]), true, 0, &aux, gcol_rows);
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gconv, (T*)(base + w.gbuf[1]), true, 0, &aux, gcol_rows, fs);
 }
 
 extern "C" int cp_encoder_backward_ev(const cp_config* cfg, const cp_params* p, const float* x, void* ws, size_t ws_bytes,

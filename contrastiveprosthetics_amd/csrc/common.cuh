@@ -98,6 +98,13 @@ __device__ __forceinline__ uint4 f8_chunk_to_bf16(const uint2& raw, float d) {
     return make_uint4(pack2bf(v[0] * d, v[1] * d), pack2bf(v[2] * d, v[3] * d), pack2bf(v[4] * d, v[5] * d), pack2bf(v[6] * d, v[7] * d));
 }
 
+// 8 e5m2 bytes times d -> one 16-byte chunk of bf16 (exact: two mantissa bits, power-of-two scale)
+__device__ __forceinline__ uint4 f8_chunk5_to_bf16(const uint2& raw, float d) {
+    const auto a = __builtin_amdgcn_cvt_pk_f32_bf8((int)raw.x, false), b = __builtin_amdgcn_cvt_pk_f32_bf8((int)raw.x, true);
+    const auto c = __builtin_amdgcn_cvt_pk_f32_bf8((int)raw.y, false), e = __builtin_amdgcn_cvt_pk_f32_bf8((int)raw.y, true);
+    return make_uint4(pack2bf(a[0] * d, a[1] * d), pack2bf(b[0] * d, b[1] * d), pack2bf(c[0] * d, c[1] * d), pack2bf(e[0] * d, e[1] * d));
+}
+
 // ---- MFMA on one 16-byte chunk pair ---------------------------------------------
 // a: chunk of the MFMA "A" operand row (lane&31), k-range selected by lane>>5
 // b: chunk of the MFMA "B" operand column (lane&31), same k-range.

@@ -10,6 +10,7 @@
 // are the same image read at row offsets 0/1/2 and the zero padding is real zeros.  Blocks are
 // persistent (weights stay in LDS, BN partial sums stay in registers across strips).
 #pragma once
+#include <type_traits>
 #include "common.cuh"
 #include "gemm_tn.cuh"
 
@@ -24,7 +25,8 @@ struct ConvArgs {
     const float* stats1;    // BN1 [4][64] mean, invstd, scale, shift (nullptr: image holds raw r1)
     const void* wc;         // conv2 weights in compute dtype [64][192] (k = tap*64 + in-channel)
     const float* bias2;     // conv_emg.3.bias (forward)
-    const void* gin;        // [N*12][64] T gradient wrt conv2's pre-BN output (dgrad / wgrad)
+    const void* gin;        // [N*12][64] T gradient wrt conv2's pre-BN output (dgrad / wgrad); kernels with G8: e5m2 bytes, stored = value * 2^*gin_exp
+    const int* gin_exp;
     const float* coef;      // conv2_dgrad_conv1_kernel: BatchNorm1-backward coefficients [3][64] (bn_bwd_finalize_kernel)
     void* out;              // forward: r2, dgrad: g_v1   [N*12][64] T
     uint8_t* out8;          // forward, CP_FP8: r2 as e4m3 [N*12][64] INSTEAD of `out`, scale 2^*out_exp, running maximum in *out_amax
@@ -419,8 +421,10 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
 // ------------------------------------------------------------------------------------------
 #define CONV_WG_WPB 8                                  // windows per strip of the weight-gradient kernel
 #define CONV_WG_IMG (CONV_WG_WPB * 14)                 // 112 image rows (a multiple of the 16-row k-step)
-template <typename T>
+template <typename T, bool G8 = false>
 __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
+    static_assert(!G8 || sizeof(T) == 2, "e5m2 gradients are expanded into a bf16 image");
+    using GV = std::conditional_t<G8, uint2, uint4>;         // one 8-channel chunk of the gradient as it sits in memory
     using D = DT<T>;
     using G = ConvGeo<T>;
     constexpr int EPC = G::EPC, CPR = G::CPR, RPP = G::RPP, KSTEP = D::KSTEP;
@@ -460,8 +464,10 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
     // The strip's global loads (the gradient rows and the three inputs under conv1's taps, per image row of this thread)
     // are requested one strip ahead, right behind the barrier that publishes the current images, and land under the
     // MFMA phase: 28 more live registers (two blocks per CU instead of three), no exposed load latency.
-    uint4 xg[NIT];
+    GV xg[NIT];
     float xr[NIT][3];
+    float gd = 1.f;
+    if constexpr (G8) gd = f8_exp2i(-*a.gin_exp);
     auto prefetch = [&](int64_t strip) {
         const int64_t win0 = strip * CONV_WG_WPB;
 #pragma unroll
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
             const bool ok = strip < nstrips && ir < CONV_WG_IMG && wp >= 1 && wp <= 12 && win < a.n_windows;
             const int64_t winc = ok ? win : 0;                     // clamped: loads are unconditional
             const int wpos = ok ? wp - 1 : 0;
-            xg[q] = *(const uint4*)((const T*)a.gin + (winc * 12 + wpos) * 64 + cc * EPC);
+            xg[q] = *(const GV*)((const unsigned char*)a.gin + ((winc * 12 + wpos) * 64 + cc * EPC) * (int64_t)sizeof(GV) / EPC);
             const float* xw = a.x + winc * 12;
             xr[q][0] = xw[wpos > 0 ? wpos - 1 : 0];
             xr[q][1] = xw[wpos];
@@ -496,7 +502,9 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
                     for (int e = 0; e < EPC; ++e) t[e] = fmaf(t[e], sc[e], sh[e]);
                 }
                 uint4 yv = D::pack(t);
-                uint4 xv = xg[q];
+                uint4 xv;
+                if constexpr (G8) xv = f8_chunk5_to_bf16(xg[q], gd);
+                else xv = xg[q];
                 if (!ok) { xv = make_uint4(0, 0, 0, 0); yv = make_uint4(0, 0, 0, 0); }
                 if (ir < CONV_WG_IMG) {
                     *(uint4*)(Xi + (ir + 1) * PITCH + cc * 16) = xv;
@@ -550,8 +558,10 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
 // no output tile in LDS.  Replaces conv2_strip_kernel<T, 1> + conv1_bwd_kernel: 258 MB less written and 266 MB less read per
 // step at 167,936 windows.
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool G8 = false>
 __global__ __launch_bounds__(256, 2) void conv2_dgrad_conv1_kernel(ConvArgs a) {
+    static_assert(!G8 || sizeof(T) == 2, "e5m2 gradients are expanded into a bf16 image");
+    using GV = std::conditional_t<G8, uint2, uint4>;
     using D = DT<T>;
     using G = ConvGeo<T>;
     constexpr int EPC = G::EPC, CPR = G::CPR, ROWB = G::ROWB, RPP = G::RPP, WPITCH = G::WPITCH;
@@ -588,7 +598,9 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_conv1_kernel(ConvArgs a) {
     };
     const int xslot = (tid / 12) * 16 + 1 + tid % 12;          // (tid < 192)
     constexpr int NITG = CONV_IMG_ROWS / RPP;
-    uint4 pg[NITG];
+    GV pg[NITG];
+    float gd = 1.f;
+    if constexpr (G8) gd = f8_exp2i(-*a.gin_exp);
     auto prefetch_g = [&](int64_t strip) {
 #pragma unroll
         for (int it = 0; it < NITG; ++it) {
@@ -596,8 +608,8 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_conv1_kernel(ConvArgs a) {
             const int nl = ir / 14, wp = ir % 14;
             const int64_t win = strip * CONV_WPB + nl;
             const bool ok = strip < nstrips && wp >= 1 && wp <= 12 && win < a.n_windows;
-            pg[it] = *(const uint4*)((const T*)a.gin + ((ok ? win : 0) * 12 + (ok ? wp - 1 : 0)) * 64 + cc * EPC);
-            if (!ok) pg[it] = make_uint4(0, 0, 0, 0);
+            pg[it] = *(const GV*)((const unsigned char*)a.gin + (((ok ? win : 0) * 12 + (ok ? wp - 1 : 0)) * 64 + cc * EPC) * (int64_t)sizeof(GV) / EPC);
+            if (!ok) pg[it] = GV{};
         }
     };
     __syncthreads();                                   // (the zeroed pads before the first x values)
@@ -614,7 +626,10 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_conv1_kernel(ConvArgs a) {
         const int64_t win0 = strip * CONV_WPB;
         const float x_next = load_x(strip + gridDim.x);
 #pragma unroll
-        for (int it = 0; it < NITG; ++it) *(uint4*)(img + G::img_off(rr + it * RPP, cc)) = pg[it];
+        for (int it = 0; it < NITG; ++it) {
+            if constexpr (G8) *(uint4*)(img + G::img_off(rr + it * RPP, cc)) = f8_chunk5_to_bf16(pg[it], gd);
+            else *(uint4*)(img + G::img_off(rr + it * RPP, cc)) = pg[it];
+        }
         __syncthreads();
         prefetch_g(strip + gridDim.x);
         f32x16 acc[3];

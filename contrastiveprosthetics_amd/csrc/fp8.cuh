@@ -1359,3 +1359,14 @@ __global__ void debug_bn_dropout8_f32_kernel(const uint8_t* __restrict__ r, cons
         out[i] = fmaf(v, stats[2 * C + f], stats[3 * C + f]) * dropout_scale(pr, (int)(f & 1u), thresh, inv_keep);
     }
 }
+
+// e5m2 tensor -> bf16 in true units (the gradient tap of the tests)
+__global__ __launch_bounds__(256) void dequant5_bf16_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int64_t n4,
+                                                            const Fp8State* __restrict__ st, int t) {
+    const float d = f8_exp2i(-st->e[t]);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[4];
+        f8_unpack4_e5m2(*(const uint32_t*)(in + i * 4), v);
+        *(uint2*)(out + i * 4) = make_uint2(pack2bf(v[0] * d, v[1] * d), pack2bf(v[2] * d, v[3] * d));
+    }
+}

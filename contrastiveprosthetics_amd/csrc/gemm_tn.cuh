@@ -216,3 +216,153 @@ static inline hipError_t launch_gemm_tn(const GemmTNArgs& a, int splits, hipStre
     hipLaunchKernelGGL((gemm_tn_kernel<T, BP, BQ, YLOAD>), grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The projection's weight gradient behind fc7's dropout, and fc7's BatchNorm-backward sums with it (round 4): ONE pass over the
+// saved activation r8 where round 3 made two (gemm_tn_kernel<.., YLOAD_BNDROP> for dW, proj_dgrad_kernel<0> for the sums).
+// With keep[m][f] the forward pass's dropout decision, u8 = keep (s r8 + t) / (1 - p) and g = keep (dz Wp) / (1 - p):
+//     A[j][f] = sum_m dz[m][j] keep[m][f] r8[m][f]          B[j][f] = sum_m dz[m][j] keep[m][f]
+//     dWp[j][f] = (s[f] A + t[f] B) / (1 - p)
+//     sum_m g[m][f] = sum_j Wp[j][f] B[j][f] / (1 - p)      sum_m g[m][f] r8[m][f] = sum_j Wp[j][f] A[j][f] / (1 - p)
+// so the kernel needs no BatchNorm arithmetic at all: the Y operand of A is r8 with the dropped elements' bits cleared (one AND per
+// two elements), the Y operand of B is the constant 1.0 under the same mask, and one hash chain per four elements serves both.
+// 32 rows per step, 128 features per workgroup (wave w: features 32w..32w+31 of both products), dz's 16 live columns in a 32-column
+// X tile; slabs[split][32][512]: rows 0..15 = A, 16..31 = B (raw: proj_wgrad_finish_kernel applies 1 / (1 - p), s, t and, for an
+// e4m3 r8, its scale).  F8: r8 is stored as e4m3 bytes (expanded exactly into the bf16 tile).
+// ------------------------------------------------------------------------------------------------------------------------
+struct ProjWgradArgs {
+    const bf16_t* dz;       // [M][64], columns >= 16 zero (cp_head)
+    const void* R;          // [M][512] bf16, or e4m3 bytes
+    float* slabs;           // [S][32][512]
+    int64_t M, rows_per_split;
+    uint32_t dp_thresh, dp_key;
+    const uint32_t* dp_salt;
+};
+
+template <bool F8>
+__global__ __launch_bounds__(256) void proj_wgrad_sums_kernel(ProjWgradArgs a) {
+    constexpr int PX = TNPitch<bf16_t, 32>::value, PY = TNPitch<bf16_t, 128>::value;
+    constexpr int XB = 32 * PX, YB = 32 * PY, BUF = XB + 2 * YB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.x * 128;
+    const int64_t mb = (int64_t)blockIdx.y * a.rows_per_split;
+    int64_t me = mb + a.rows_per_split;
+    if (me > a.M) me = a.M;
+    const int nsteps = (int)((me - mb + 31) / 32);
+    const uint32_t key = a.dp_salt ? (a.dp_key ^ *a.dp_salt) : a.dp_key;
+    uint4 xreg, ya[2], yb[2];
+    auto load_tiles = [&](int step) {
+        const int64_t ms = mb + (int64_t)step * 32;
+        {
+            const int row = tid >> 2, ch = tid & 3;
+            const int64_t m = ms + row;
+            xreg = make_uint4(0, 0, 0, 0);
+            if (tid < 128 && m < me) xreg = *(const uint4*)(a.dz + m * 64 + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 4, ch = idx & 15;
+            const int64_t m = ms + row;
+            uint4 v = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
+            if (m < me) {
+                if constexpr (F8) v = f8_chunk_to_bf16(*(const uint2*)((const uint8_t*)a.R + m * 512 + q0 + ch * 8), 1.f);
+                else v = *(const uint4*)((const bf16_t*)a.R + m * 512 + q0 + ch * 8);
+                const uint2 d0 = dropout_quad(key, (uint32_t)m, 512u, (uint32_t)(q0 + ch * 8));
+                const uint2 d1 = dropout_quad(key, (uint32_t)m, 512u, (uint32_t)(q0 + ch * 8 + 4));
+                auto word_mask = [&](uint32_t dr) {
+                    return ((dr & 0xFFFFu) >= a.dp_thresh ? 0xFFFFu : 0u) | ((dr >> 16) >= a.dp_thresh ? 0xFFFF0000u : 0u);
+                };
+                const uint32_t m0 = word_mask(d0.x), m1 = word_mask(d0.y), m2 = word_mask(d1.x), m3 = word_mask(d1.y);
+                v = make_uint4(v.x & m0, v.y & m1, v.z & m2, v.w & m3);
+                o = make_uint4(0x3F803F80u & m0, 0x3F803F80u & m1, 0x3F803F80u & m2, 0x3F803F80u & m3);
+            }
+            ya[i] = v;
+            yb[i] = o;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char* Xs = smem + buf * BUF;
+        unsigned char* As = Xs + XB;
+        unsigned char* Bs = As + YB;
+        if (tid < 128) *(uint4*)(Xs + (tid >> 2) * PX + (tid & 3) * 16) = xreg;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 4, ch = idx & 15;
+            *(uint4*)(As + row * PY + ch * 16) = ya[i];
+            *(uint4*)(Bs + row * PY + ch * 16) = yb[i];
+        }
+    };
+    f32x16 accA, accB;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) accA[g] = accB[g] = 0.f;
+    if (nsteps > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) load_tiles(step + 1);
+        const unsigned char* Xs = smem + (step & 1) * BUF;
+        const unsigned char* As = Xs + XB;
+        const unsigned char* Bs = As + YB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 fx = tn_frag_bf16<PX>(Xs, ks * 16, 0, lane);
+            const uint4 fa = tn_frag_bf16<PY>(As, ks * 16, wave * 32, lane);
+            const uint4 fb = tn_frag_bf16<PY>(Bs, ks * 16, wave * 32, lane);
+            mma_chunk<bf16_t>(fx, fa, accA);
+            mma_chunk<bf16_t>(fx, fb, accB);
+        }
+        if (step + 1 < nsteps) store_tiles((step + 1) & 1);
+        __syncthreads();
+    }
+    // D[p = dz column][q = feature]: accumulator g holds p = (g & 3) + 8 (g >> 2) + 4 h -- the 16 live columns are g < 8
+    float* slab = a.slabs + (int64_t)blockIdx.y * 32 * 512;
+    const int r = lane & 31, h = lane >> 5, q = q0 + wave * 32 + r;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int pcol = (g & 3) + 8 * (g >> 2) + 4 * h;
+        slab[pcol * 512 + q] = accA[g];
+        slab[(16 + pcol) * 512 + q] = accB[g];
+    }
+}
+
+// slabs -> the projection's weight gradient (reference layout [16][512]) and ONE partial row [2][512] of fc7's BatchNorm-backward
+// sums in bn_bwd_finalize_kernel's layout.  grid 32 blocks (16 features each) x 256 threads (feature, dz column).
+// r_exp (e4m3 r8, else nullptr): its scale exponent.  Wp enters the sums rounded to bf16, as the data-gradient launch reads it.
+__global__ __launch_bounds__(256) void proj_wgrad_finish_kernel(const float* __restrict__ slabs, int S, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ Wp,
+                                                                float inv_keep, const int* __restrict__ r_exp, float* __restrict__ dWp,
+                                                                float* __restrict__ row) {
+    __shared__ float red[2][16][16];
+    const int tid = threadIdx.x, fl = tid & 15, j = tid >> 4, f = blockIdx.x * 16 + fl;
+    const float* pa = slabs + j * 512 + f;
+    const float* pb = pa + 16 * 512;
+    // (eight slabs of both products per pass: sixteen loads in flight per thread, a fixed order of additions)
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+        float va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { va[u] = pa[(int64_t)(k + u) * 32 * 512]; vb[u] = pb[(int64_t)(k + u) * 32 * 512]; }
+        a0 += (va[0] + va[2]) + (va[4] + va[6]);
+        a1 += (va[1] + va[3]) + (va[5] + va[7]);
+        b0 += (vb[0] + vb[2]) + (vb[4] + vb[6]);
+        b1 += (vb[1] + vb[3]) + (vb[5] + vb[7]);
+    }
+    for (; k < S; ++k) { a0 += pa[(int64_t)k * 32 * 512]; b0 += pb[(int64_t)k * 32 * 512]; }
+    const float A = (a0 + a1) * inv_keep * (r_exp ? f8_exp2i(-*r_exp) : 1.f), B = (b0 + b1) * inv_keep;
+    dWp[j * 512 + f] = fmaf(scale[f], A, shift[f] * B);
+    const float w = bf2f(f2bf(Wp[j * 512 + f]));
+    red[0][j][fl] = w * B;
+    red[1][j][fl] = w * A;
+    __syncthreads();
+    if (tid < 32) {
+        const int which = tid >> 4, c = tid & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[which][q][c];
+        row[which * 512 + blockIdx.x * 16 + c] = s;
+    }
+}

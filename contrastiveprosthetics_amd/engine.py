@@ -233,9 +233,11 @@ class Engine:
         self._sync_world = 1
         self._fp8_seen_forward = False
         # second stream for the weight gradients that nothing in the step waits for (cp_config.aux_stream; include/cpnative.h): created on
-        # first use; None/False = one stream.  $CPNATIVE_AUX_STREAM=0 switches it off for A/B runs.
+        # first use; None/False = one stream.  OFF by default since the projection's and conv2's weight gradients moved onto the critical
+        # path (their products carry BatchNorm-backward sums): one stream measured 0.01-0.04 ms per step faster than two on the same box
+        # (DESIGN 7i); $CPNATIVE_AUX_STREAM=1 or engine.aux_stream_enabled = True switches it on.
         import os as _os
-        self.aux_stream_enabled = _os.environ.get("CPNATIVE_AUX_STREAM", "1") != "0"
+        self.aux_stream_enabled = _os.environ.get("CPNATIVE_AUX_STREAM", "0") == "1"
         self._aux = None
         self.grad_tap: Optional[torch.Tensor] = None          # test aid (cp_config.grad_tap)
         self._ws: Optional[torch.Tensor] = None

@@ -358,7 +358,11 @@ def recompute_check(n_groups=B, p_drop=P_DROP, data_seed=6, dtype="bf16"):
 
     # ---------------- backward --------------------------------------------------------------------------------------
     # projection: dW = dz^T u8 (dz is stored in bf16 by the head kernel, so this bound carries its rounding)
-    check_param("bwd/last_w", G["emg_net.last.0.weight"], dz.t() @ u8, tol=1e-3)
+    # (round 4, behind a dropout: dW = (s A + t B) / (1 - p) from the two raw products of proj_wgrad_sums_kernel, i.e. against u8 BEFORE its
+    #  rounding to the storage type; without dropout the stored BN output is the operand, as before)
+    u8x = (acts[8] * st[8][2] + st[8][3]) * masks[8] * inv_keep if drop else u8
+    check_param("bwd/last_w", G["emg_net.last.0.weight"], dz.t() @ u8x, tol=1e-3)
+    del u8x
     gv = (dz @ W["emg_net.last.0.weight"]) * masks[8] * inv_keep
     gamma = W[bnn[8] + ".weight"]
     g_ref, dg, db_ = _bn_backward(gv, acts[8], st[8][0], st[8][1], gamma, N)
