@@ -1579,13 +1579,13 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
             sl = folded;
             ns = REDUCE_SLICES;
         }
-        hipLaunchKernelGGL((conv2_wgrad_finish_kernel<T>), dim3(32), dim3(256), 0, st, sl, ns, partials, gcol_rows, p->conv2_w, stats(0),
+        hipLaunchKernelGGL((conv2_wgrad_finish_kernel<T>), dim3(CONV2_FINISH_ROWS), dim3(256), 0, st, sl, ns, partials, gcol_rows, p->conv2_w, stats(0),
                            g->conv2_w, rows2);
         CKL("conv2_wgrad_finish_kernel");
     }
     {
         ProfScope ps(CP_K_BN_BWD, st);
-        if (int e = bwd_finalize(rows2, 32, (double)R12, 0, 64, 1, "bn_bwd_finalize_kernel(conv1)")) return e;
+        if (int e = bwd_finalize(rows2, CONV2_FINISH_ROWS, (double)R12, 0, 64, 1, "bn_bwd_finalize_kernel(conv1)")) return e;
     }
     const int grid_d = conv_grid<T>(N);
     ca.wc = base + w.wc2_d; ca.coef = coef;
@@ -1702,7 +1702,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
                 pa.dp_thresh = dp_thresh(c->dp_emg); pa.dp_key = dp_key(c, 8); pa.dp_salt = dp_salt(c);
                 hipLaunchKernelGGL(proj_wgrad_sums_kernel<false>, dim3(4, S), dim3(256), 0, st, pa);
                 CKL("proj_wgrad_sums_kernel");
-                hipLaunchKernelGGL(proj_wgrad_finish_kernel, dim3(32), dim3(256), 0, st, slabs, S, stats(8) + 2 * 512, stats(8) + 3 * 512, p->last_w,
+                hipLaunchKernelGGL(proj_wgrad_finish_kernel, dim3(32, PROJ_FINISH_ROWS), dim3(256), 0, st, slabs, S, stats(8) + 2 * 512, stats(8) + 3 * 512, p->last_w,
                                    dp_inv_keep(c->dp_emg), (const int*)nullptr, g->last_w, partials);
                 CKL("proj_wgrad_finish_kernel");
             }
@@ -1753,7 +1753,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // behind fc7's dropout: the rank-16 product is formed with fc7's BN + ReLU backward applied (gemm_ws.cuh, proj_dgrad_kernel<1>)
             // instead of being written out for a separate bn_relu_bwd pass; the BatchNorm-backward sums it needs came with the weight
             // gradient above (round 3 and the tools build: a first pass of the same product, proj_dgrad_kernel<0>)
-            int nr = 1;
+            int nr = PROJ_FINISH_ROWS;
             const float* pp = partials;
             if (!proj_alg) {
                 CK(launch_proj_dgrad<0>(a, st, &drows));
@@ -1987,7 +1987,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             pa.dp_thresh = dp_thresh(c->dp_emg); pa.dp_key = dp_key(c, 8); pa.dp_salt = dp_salt(c);
             hipLaunchKernelGGL(proj_wgrad_sums_kernel<true>, dim3(4, S), dim3(256), 0, st, pa);
             CKL("proj_wgrad_sums_kernel<e4m3>");
-            hipLaunchKernelGGL(proj_wgrad_finish_kernel, dim3(32), dim3(256), 0, st, slabs, S, stats(8) + 2 * 512, stats(8) + 3 * 512, p->last_w,
+            hipLaunchKernelGGL(proj_wgrad_finish_kernel, dim3(32, PROJ_FINISH_ROWS), dim3(256), 0, st, slabs, S, stats(8) + 2 * 512, stats(8) + 3 * 512, p->last_w,
                                dp_inv_keep(c->dp_emg), (const int*)&fs->e[F8_T_ACT + 8], g->last_w, partials);
             CKL("proj_wgrad_finish_kernel");
         } else {
@@ -2002,7 +2002,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         int drows = 0;
         if (drop) {
             a.dp_thresh = dp_thresh(c->dp_emg); a.dp_key = dp_key(c, 8); a.dp_inv_keep = dp_inv_keep(c->dp_emg); a.dp_salt = dp_salt(c);
-            if (int e = bwd_finalize(partials, 1, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
+            if (int e = bwd_finalize(partials, PROJ_FINISH_ROWS, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
         } else {
             // no dropout behind fc7: its BatchNorm-backward sums follow from the projection's weight gradient (no N-sized read)
             hipLaunchKernelGGL(bn_bwd_sums_from_wgrad_kernel, dim3(512 / 64, 1), dim3(256), 0, st, praw, p->last_w, dzsum, partials, CP_D_E, 512, 0);

@@ -7,9 +7,10 @@
 #include "common.cuh"
 
 constexpr int SV_T = 41;            // classes
-constexpr int SV_MPB = 32;          // subsets handled by one block
+constexpr int SV_MPB = 8;           // subsets handled by one block (round 4: 32 made 2 x B blocks of ~40k serial instructions per thread --
+                                    // 257 us for 64 subsets of 160 groups x 25 samples, most of the chip idle)
 constexpr int SV_VMAX = 64;         // samples per group supported
-constexpr int SV_VCHUNK = 4;        // logits tiles staged per pass
+constexpr int SV_VCHUNK = 6;        // logits tiles staged per pass: 6 x 41 rows keep 246 of the 256 threads busy
 constexpr int SV_TILE = SV_T * SV_T;
 
 struct SubsetVoteArgs {
@@ -23,7 +24,7 @@ struct SubsetVoteArgs {
 };
 
 // grid (ceil(n_masks / SV_MPB), B), 256 threads, dynamic LDS = sv_lds_bytes(V).
-// Phase 1: the group's 41 x 41 logits tiles pass through LDS four samples at a time; thread (t, v) keeps
+// Phase 1: the group's 41 x 41 logits tiles pass through LDS six samples at a time; thread (t, v) keeps
 // its row in registers and takes the arg-max over the member columns of each of the block's subsets
 // (first maximum wins) -> preds[m][v][t] (one byte each).
 // Phase 2: thread per (subset, row): running histogram of the V predictions, mode with ties to the
@@ -53,14 +54,14 @@ __global__ __launch_bounds__(256) void subset_vote_kernel(SubsetVoteArgs a) {
     }
     for (int i = tid; i < SV_MPB * V; i += 256) hits[i] = 0;
 
-    const int t = tid & 63, vs = tid >> 6;
+    const int vs = tid / SV_T, t = tid % SV_T;              // (vs up to 6: threads 246..255 idle in phase 1)
     for (int v0 = 0; v0 < V; v0 += SV_VCHUNK) {
         __syncthreads();                                     // previous pass done with `tile` (and bits/hits written)
         const int nv = (V - v0 < SV_VCHUNK) ? (V - v0) : SV_VCHUNK;
         const float* src = a.logits + ((b * V + v0) * (int64_t)SV_TILE);
         for (int i = tid; i < nv * SV_TILE; i += 256) tile[i] = src[i];
         __syncthreads();
-        if (t < SV_T && vs < nv) {
+        if (vs < nv) {
             float x[SV_T];
 #pragma unroll
             for (int c = 0; c < SV_T; ++c) x[c] = tile[vs * SV_TILE + t * SV_T + c];

@@ -328,41 +328,49 @@ __global__ __launch_bounds__(256) void proj_wgrad_sums_kernel(ProjWgradArgs a) {
     }
 }
 
-// slabs -> the projection's weight gradient (reference layout [16][512]) and ONE partial row [2][512] of fc7's BatchNorm-backward
-// sums in bn_bwd_finalize_kernel's layout.  grid 32 blocks (16 features each) x 256 threads (feature, dz column).
+// slabs -> the projection's weight gradient (reference layout [16][512]) and FOUR partial rows [2][512] of fc7's BatchNorm-backward
+// sums in bn_bwd_finalize_kernel's layout (row y sums dz columns 4y..4y+3).  grid (32, 4) blocks x 256 threads = 16 features x 4 dz
+// columns x 4 slab quarters: a thread walks every fourth slab, eight loads of both products in flight, 64-byte segments per wave
+// row (a fixed order of additions; 32 blocks of whole-S walks took 14 us).
 // r_exp (e4m3 r8, else nullptr): its scale exponent.  Wp enters the sums rounded to bf16, as the data-gradient launch reads it.
+#define PROJ_FINISH_ROWS 4
 __global__ __launch_bounds__(256) void proj_wgrad_finish_kernel(const float* __restrict__ slabs, int S, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ Wp,
                                                                 float inv_keep, const int* __restrict__ r_exp, float* __restrict__ dWp,
-                                                                float* __restrict__ row) {
-    __shared__ float red[2][16][16];
-    const int tid = threadIdx.x, fl = tid & 15, j = tid >> 4, f = blockIdx.x * 16 + fl;
+                                                                float* __restrict__ rows) {
+    __shared__ float part[2][4][4][16];
+    __shared__ float red[2][4][16];
+    const int tid = threadIdx.x, fl = tid & 15, jl = (tid >> 4) & 3, sh = tid >> 6;
+    const int f = blockIdx.x * 16 + fl, j = blockIdx.y * 4 + jl;
     const float* pa = slabs + j * 512 + f;
     const float* pb = pa + 16 * 512;
-    // (eight slabs of both products per pass: sixteen loads in flight per thread, a fixed order of additions)
+    const int64_t sstride = 32 * 512;
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-    int k = 0;
-    for (; k + 8 <= S; k += 8) {
+    int k = sh;
+    for (; k + 28 < S; k += 32) {
         float va[8], vb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { va[u] = pa[(int64_t)(k + u) * 32 * 512]; vb[u] = pb[(int64_t)(k + u) * 32 * 512]; }
+        for (int u = 0; u < 8; ++u) { va[u] = pa[(k + 4 * u) * sstride]; vb[u] = pb[(k + 4 * u) * sstride]; }
         a0 += (va[0] + va[2]) + (va[4] + va[6]);
         a1 += (va[1] + va[3]) + (va[5] + va[7]);
         b0 += (vb[0] + vb[2]) + (vb[4] + vb[6]);
         b1 += (vb[1] + vb[3]) + (vb[5] + vb[7]);
     }
-    for (; k < S; ++k) { a0 += pa[(int64_t)k * 32 * 512]; b0 += pb[(int64_t)k * 32 * 512]; }
-    const float A = (a0 + a1) * inv_keep * (r_exp ? f8_exp2i(-*r_exp) : 1.f), B = (b0 + b1) * inv_keep;
-    dWp[j * 512 + f] = fmaf(scale[f], A, shift[f] * B);
-    const float w = bf2f(f2bf(Wp[j * 512 + f]));
-    red[0][j][fl] = w * B;
-    red[1][j][fl] = w * A;
+    for (; k < S; k += 4) { a0 += pa[k * sstride]; b0 += pb[k * sstride]; }
+    part[0][sh][jl][fl] = a0 + a1;
+    part[1][sh][jl][fl] = b0 + b1;
+    __syncthreads();
+    if (sh == 0) {
+        const float A = ((part[0][0][jl][fl] + part[0][1][jl][fl]) + (part[0][2][jl][fl] + part[0][3][jl][fl])) * inv_keep * (r_exp ? f8_exp2i(-*r_exp) : 1.f);
+        const float B = ((part[1][0][jl][fl] + part[1][1][jl][fl]) + (part[1][2][jl][fl] + part[1][3][jl][fl])) * inv_keep;
+        dWp[j * 512 + f] = fmaf(scale[f], A, shift[f] * B);
+        const float w = bf2f(f2bf(Wp[j * 512 + f]));
+        red[0][jl][fl] = w * B;
+        red[1][jl][fl] = w * A;
+    }
     __syncthreads();
     if (tid < 32) {
         const int which = tid >> 4, c = tid & 15;
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) s += red[which][q][c];
-        row[which * 512 + blockIdx.x * 16 + c] = s;
+        rows[((int64_t)blockIdx.y * 2 + which) * 512 + blockIdx.x * 16 + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
     }
 }

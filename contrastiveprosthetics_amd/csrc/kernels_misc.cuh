@@ -562,66 +562,65 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
 //     S2[c] = sum_{n,p} g_v1[n][p][c] r1[n][p][c] = sum_{o,tap} W2[o][c][tap] P[o][tap][c]
 // (g_v1 = conv2's data gradient; W2 rounded as the data-gradient kernel's operand is).  gcols: nr partial rows [768] of the column
 // sums of g seen as [N][q * 64 + o] -- the bias-gradient rows fc1's data-gradient launch wrote, or colsum_kernel's.
-// grid 32 blocks (two output channels each) x 256 threads; out_rows[32][2][64] in bn_bwd_finalize_kernel's layout.
+// grid CONV2_FINISH_ROWS = 64 blocks (one output channel each) x 256 threads; out_rows[64][2][64] in bn_bwd_finalize_kernel's layout.
 // ------------------------------------------------------------------------------------
+#define CONV2_FINISH_ROWS 64
 template <typename T>
 __global__ __launch_bounds__(256) void conv2_wgrad_finish_kernel(const float* __restrict__ slabs, int S, const float* __restrict__ gcols, int nr,
                                                                  const float* __restrict__ W2, const float* __restrict__ stats1,
                                                                  float* __restrict__ dW2, float* __restrict__ out_rows) {
     using D = DT<T>;
-    __shared__ double part[10][24];
-    __shared__ float Gs[2][3];
-    __shared__ float red[2][6][64];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    if (tid < 240) {
-        const int pi = tid % 24, ls = tid / 24, ol = pi / 12, q = pi % 12;
+    __shared__ double part[21][12];
+    __shared__ float Gs[3];
+    __shared__ float red[2][3][64];
+    const int tid = threadIdx.x, o = blockIdx.x;
+    if (tid < 252) {
+        const int q = tid % 12, ls = tid / 12;
         double s = 0;
-        for (int rw = ls; rw < nr; rw += 10) s += (double)gcols[(int64_t)rw * 768 + q * 64 + 2 * b + ol];
-        part[ls][pi] = s;
+        for (int rw = ls; rw < nr; rw += 21) s += (double)gcols[(int64_t)rw * 768 + q * 64 + o];
+        part[ls][q] = s;
     }
     __syncthreads();
-    if (tid < 2) {
-        double cs[12], all = 0;
-        for (int q = 0; q < 12; ++q) {
-            double s = 0;
-            for (int ls = 0; ls < 10; ++ls) s += part[ls][tid * 12 + q];
-            cs[q] = s;
-            all += s;
-        }
-        Gs[tid][0] = (float)(all - cs[0]);
-        Gs[tid][1] = (float)all;
-        Gs[tid][2] = (float)(all - cs[11]);
+    if (tid < 12) {
+        double s = 0;
+        for (int ls = 0; ls < 21; ++ls) s += part[ls][tid];
+        part[0][tid] = s;                              // (column tid: only this thread read it)
     }
     __syncthreads();
-    for (int e = tid; e < 384; e += 256) {
-        const int ol = e / 192, q = e % 192, tap = q >> 6, c = q & 63, o = 2 * b + ol;
-        const float* src = slabs + o * 192 + q;
+    if (tid == 0) {
+        double all = 0;
+        for (int q = 0; q < 12; ++q) all += part[0][q];
+        Gs[0] = (float)(all - part[0][0]);
+        Gs[1] = (float)all;
+        Gs[2] = (float)(all - part[0][11]);
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int tap = tid >> 6, c = tid & 63;
+        const float* src = slabs + o * 192 + tid;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int k = 0;
-        for (; k + 4 <= S; k += 4) {
-            a0 += src[(int64_t)(k + 0) * 64 * 192];
-            a1 += src[(int64_t)(k + 1) * 64 * 192];
-            a2 += src[(int64_t)(k + 2) * 64 * 192];
-            a3 += src[(int64_t)(k + 3) * 64 * 192];
+        for (; k + 8 <= S; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + u) * 64 * 192];
+            a0 += v[0] + v[4]; a1 += v[1] + v[5]; a2 += v[2] + v[6]; a3 += v[3] + v[7];
         }
         for (; k < S; ++k) a0 += src[(int64_t)k * 64 * 192];
         const float P = (a0 + a1) + (a2 + a3);
-        const float G = Gs[ol][tap];
+        const float G = Gs[tap];
         const int base = (o * 64 + c) * 9;
         dW2[base + 3 + tap] = fmaf(stats1[2 * 64 + c], P, stats1[3 * 64 + c] * G);
         dW2[base + 0 + tap] = 0.f;
         dW2[base + 6 + tap] = 0.f;
         const float w = D::round(W2[base + 3 + tap]);
-        red[0][ol * 3 + tap][c] = w * G;
-        red[1][ol * 3 + tap][c] = w * P;
+        red[0][tap][c] = w * G;
+        red[1][tap][c] = w * P;
     }
     __syncthreads();
     if (tid < 128) {
         const int which = tid >> 6, c = tid & 63;
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s += red[which][k][c];
-        out_rows[((int64_t)b * 2 + which) * 64 + c] = s;
+        out_rows[((int64_t)o * 2 + which) * 64 + c] = (red[which][0][c] + red[which][1][c]) + red[which][2][c];
     }
 }
 
