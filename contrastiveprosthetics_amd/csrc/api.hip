@@ -523,7 +523,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         constexpr int RPP = 256 / (64 / D::EPC);                      // windows per block and pass
         const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
         const int g = (int)((need + passes - 1) / passes);            // every block makes the same number of passes
-        {
+        if (batch_stats) {                               // (evaluation with running statistics needs nothing of conv1 but its recomputation)
             ProfScope ps(CP_K_CONV1_FWD, st);
             // statistics only: r1 is never stored, its consumers recompute it from x (conv_kernels.cuh)
             hipLaunchKernelGGL((conv1_stats_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, partials, R12);
@@ -684,7 +684,7 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
         constexpr int RPP = 256 / (64 / D::EPC);
         const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
         const int g = (int)((need + passes - 1) / passes);
-        {
+        if (batch_stats) {
             ProfScope ps(CP_K_CONV1_FWD, st);
             hipLaunchKernelGGL((conv1_stats_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, partials, R12);
             CKL("conv1_stats_kernel");
@@ -856,7 +856,7 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
 
 template <typename T> static int conv_backward_tail(const cp_config*, const cp_params*, const float*, unsigned char*, const WS&, cp_params*, hipStream_t,
                                                     hipEvent_t, T*, T*, bool, int, const Aux* aux = nullptr, int gcol_rows = 0,
-                                                    const Fp8State* g8 = nullptr);
+                                                    const Fp8State* g8 = nullptr, bool small = false);
 
 template <typename T>
 static int encoder_backward_small_t(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
@@ -929,7 +929,7 @@ static int encoder_backward_small_t(const cp_config* c, const cp_params* p, cons
         CKL("sm_reduce_grads_kernel");
     }
     // `partials` now holds fc1's partial sums [tiles_m][2][768]: the conv tail finalises conv2's BatchNorm backward from them
-    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gb[cur], gb[cur ^ 1], false, tiles_m);
+    return conv_backward_tail<T>(c, p, x, base, w, g, st, fc_grads_ready, gb[cur], gb[cur ^ 1], false, tiles_m, nullptr, 0, nullptr, true);
 }
 
 // Which kernel path the last forward pass over a workspace took, keyed by the workspace address: the backward pass must take the same
@@ -1484,7 +1484,9 @@ static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t
 template <typename T>
 static int conv_backward_tail(const cp_config* c, const cp_params* p, const float* x, unsigned char* base, const WS& w,
                               cp_params* g, hipStream_t st, hipEvent_t fc_grads_ready, T* cur, T* nxt, bool bn_done, int stat_rows, const Aux* aux,
-                              int gcol_rows, const Fp8State* g8) {
+                              int gcol_rows, const Fp8State* g8, bool small) {
+    // small (the small-batch step, csrc/small.cuh: !bn_done, `partials` = fc1's partial rows [stat_rows][2][768]): four launches -- every
+    // BatchNorm-backward finalisation happens in the consumer's prologue, BatchNorm2 + ReLU backward while conv2's weight gradient stages
     // g8 (CP_FP8): `cur` holds e5m2 bytes with the scale of tensor F8_T_GRAD + 1 (fc1's data-gradient launch wrote them), expanded into
     // the kernels' bf16 images while they are staged; the bias-gradient rows (gcol_rows) are in true units
     using D = DT<T>;
@@ -1517,6 +1519,57 @@ static int conv_backward_tail(const cp_config* c, const cp_params* p, const floa
         CK(hipEventRecord(fc_grads_ready, st));
     }
     // ---- conv2: cur = dL/d(BN2 output) as [N][768] == [(N*12)][64] -------------------------
+    if (small) {
+        if (bn_done || g8 || c->stats_allreduce) return fail(CP_ERR_ARG, "conv_backward_tail: small-batch form");
+        ConvArgs ca{};
+        ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = nullptr; ca.gin = cur; ca.n_windows = N;
+        float* gcols3 = (float*)(base + w.praw);
+        const int64_t strips = (N + CONV_WG_WPB - 1) / CONV_WG_WPB;
+        const int S = (int)(strips < 512 ? strips : 512);
+        {
+            ProfScope ps(CP_K_CONV2_WGRAD, st);
+            ca.partials = slabs; ca.bn2_rows = partials; ca.bn2_nr = stat_rows; ca.r2 = act(1); ca.stats2 = stats(1);
+            ca.dgamma2 = g->bn_g[1]; ca.dbeta2 = g->bn_b[1]; ca.gcols3 = gcols3;
+            hipLaunchKernelGGL((conv2_wgrad_kernel<T, false, true>), dim3(S), dim3(256), 0, st, ca);
+            CKL("conv2_wgrad_kernel<small>");
+            const float* sl = slabs;
+            int ns = S;
+            if (S > 2 * REDUCE_SLICES) {
+                float* folded = slabs + (size_t)S * 64 * 192;
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(64 * 192 / 64, REDUCE_SLICES), dim3(256), 0, st, slabs, S, 64 * 192, folded);
+                sl = folded;
+                ns = REDUCE_SLICES;
+            }
+            hipLaunchKernelGGL((conv2_wgrad_finish_kernel<T>), dim3(CONV2_FINISH_ROWS), dim3(256), 0, st, sl, ns, (const float*)nullptr, S, p->conv2_w,
+                               stats(0), g->conv2_w, rows2, (const float*)gcols3, g->conv2_b);
+            CKL("conv2_wgrad_finish_kernel<small>");
+        }
+        if (int e = tap_gradient(c, 1, cur, N, 768, sizeof(T), st)) return e;         // dL/d(conv2 pre-activation): written back in place
+        const int grid_d = conv_grid<T>(N);
+        ca.wc = base + w.wc2_d;
+        if (c->grad_tap) {
+            ca.out = nxt; ca.partials = partials;
+            hipLaunchKernelGGL((conv2_strip_kernel<T, 1>), dim3(grid_d), dim3(256), 0, st, ca);
+            CKL("conv2_strip_kernel<dgrad> (gradient tap)");
+            if (int e = tap_gradient(c, 0, nxt, N, 768, sizeof(T), st)) return e;
+        }
+        {
+            ProfScope ps(CP_K_CONV2_DGRAD, st);
+            ca.out = nullptr; ca.partials = partials; ca.stats1 = stats(0); ca.rows1 = rows2; ca.rows1_nr = CONV2_FINISH_ROWS;
+            ca.dgamma1 = g->bn_g[0]; ca.dbeta1 = g->bn_b[0];
+            hipLaunchKernelGGL((conv2_dgrad_conv1_kernel<T, false, true>), dim3(grid_d), dim3(256), 0, st, ca);
+            CKL("conv2_dgrad_conv1_kernel<small>");
+        }
+        {
+            ProfScope ps(CP_K_CONV1_BWD, st);
+            int nr = grid_d;
+            const float* pp = pre(nr, 4 * 64, 2 * REDUCE_SLICES);
+            hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, pp, nr, g->conv1_w, g->conv1_b);
+            CKL("conv1_bwd_finalize_kernel");
+        }
+        if (aux) { if (int e = aux->join()) return e; }
+        return 0;
+    }
     if (!bn_done) {
         ProfScope ps(CP_K_BN_BWD, st);
         int nr = stat_rows;          // 1: fc1's input (conv2's BN) never has dropout

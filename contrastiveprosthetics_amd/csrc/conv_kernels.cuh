@@ -38,7 +38,63 @@ struct ConvArgs {
     // replaces stats1; block 0 stores the statistics) and the output's totals added to acc_out instead of partial rows: no finalize launches
     SmBN bn1;
     long long* acc_out;     // [2][64] or nullptr
+    // small batches, backward (conv_backward_tail): the consumer finalises, no launches in between.
+    //   conv2_wgrad_kernel<T, false, true>: BatchNorm2 + ReLU backward applied to the gradient while it is staged (and written back
+    //   in place for the data-gradient launch), its coefficients formed in the prologue from fc1's partial rows
+    const float* bn2_rows;  // [bn2_nr][2][768] sums of (g, g r2) per (position, channel)
+    int bn2_nr;
+    const void* r2;         // [N*12][64] T conv2's saved output
+    const float* stats2;    // [4][64]
+    float* dgamma2;         // written by block 0
+    float* dbeta2;
+    float* gcols3;          // [grid][3][64]: column sums of the transformed gradient over all positions / position 0 / position 11
+    //   conv2_dgrad_conv1_kernel<T, false, true>: BatchNorm1's backward coefficients from conv2_wgrad_finish_kernel's rows (stats1 = its table)
+    const float* rows1;     // [rows1_nr][2][64]
+    int rows1_nr;
+    float* dgamma1;
+    float* dbeta1;
 };
+
+// coefficients of  g_y = [r > 0] (ca g + cb r + cz)  for 64 channels from `nr` partial rows [2][nfold * 64] of (sum g, sum g r)
+// (bn_bwd_finalize_kernel's arithmetic; 256 threads, every block of a launch computes the same numbers; `writer` stores dgamma / dbeta)
+__device__ __forceinline__ void conv_bn_bwd_coef(const float* __restrict__ rows, int nr, int nfold, const float* __restrict__ stats, double count,
+                                                 float* ca, float* cb, float* cz, double (*red)[4][64], bool writer, float* dgamma, float* dbeta) {
+    const int tid = threadIdx.x, c = tid & 63, part = tid >> 6, W = nfold * 64;
+    double s1 = 0, s2 = 0;
+    const int total = nr * nfold;
+    int i = part;
+    for (; i + 28 < total; i += 32) {                  // eight (row, position) pairs of both sums in flight: this walk is pure latency
+        float v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = i + 4 * u, rw = k / nfold, f = k % nfold;
+            v1[u] = rows[((int64_t)rw * 2 + 0) * W + f * 64 + c];
+            v2[u] = rows[((int64_t)rw * 2 + 1) * W + f * 64 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+    }
+    for (; i < total; i += 4) {
+        const int rw = i / nfold, f = i % nfold;
+        s1 += (double)rows[((int64_t)rw * 2 + 0) * W + f * 64 + c];
+        s2 += (double)rows[((int64_t)rw * 2 + 1) * W + f * 64 + c];
+    }
+    red[0][part][c] = s1;
+    red[1][part][c] = s2;
+    __syncthreads();
+    if (tid < 64) {
+        s1 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        s2 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+        const double mean = stats[c], invstd = stats[64 + c], sc = stats[128 + c];
+        const double dot = (s2 - mean * s1) * invstd;
+        const double c1 = s1 / count, c2 = dot / count;
+        ca[c] = (float)sc;
+        cb[c] = (float)(-sc * invstd * c2);
+        cz[c] = (float)(-sc * (c1 - mean * invstd * c2));
+        if (writer) { dgamma[c] = (float)dot; dbeta[c] = (float)s1; }
+    }
+    __syncthreads();
+}
 
 template <typename T> struct ConvGeo {
     using D = DT<T>;
@@ -421,9 +477,10 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
 // ------------------------------------------------------------------------------------------
 #define CONV_WG_WPB 8                                  // windows per strip of the weight-gradient kernel
 #define CONV_WG_IMG (CONV_WG_WPB * 14)                 // 112 image rows (a multiple of the 16-row k-step)
-template <typename T, bool G8 = false>
-__global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
+template <typename T, bool G8 = false, bool BN2 = false>
+__global__ __launch_bounds__(256, BN2 ? 1 : 2) void conv2_wgrad_kernel(ConvArgs a) {
     static_assert(!G8 || sizeof(T) == 2, "e5m2 gradients are expanded into a bf16 image");
+    static_assert(!(G8 && BN2), "the small-batch form reads T gradients");
     using GV = std::conditional_t<G8, uint2, uint4>;         // one 8-channel chunk of the gradient as it sits in memory
     using D = DT<T>;
     using G = ConvGeo<T>;
@@ -454,6 +511,20 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+    // BN2 (small batches): BatchNorm2 + ReLU backward of the staged gradient, coefficients of this thread's channels in registers
+    uint4 xr2[BN2 ? NIT : 1];
+    float c2a[BN2 ? EPC : 1], c2b[BN2 ? EPC : 1], c2z[BN2 ? EPC : 1], cs_all[BN2 ? EPC : 1], cs_first[BN2 ? EPC : 1], cs_last[BN2 ? EPC : 1];
+    if constexpr (BN2) {
+        __shared__ float ca_s[64], cb_s[64], cz_s[64];
+        conv_bn_bwd_coef(a.bn2_rows, a.bn2_nr, 12, a.stats2, (double)a.n_windows * 12, ca_s, cb_s, cz_s, (double (*)[4][64])smem, blockIdx.x == 0,
+                         a.dgamma2, a.dbeta2);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            c2a[e] = ca_s[cc * EPC + e]; c2b[e] = cb_s[cc * EPC + e]; c2z[e] = cz_s[cc * EPC + e];
+            cs_all[e] = cs_first[e] = cs_last[e] = 0.f;
+        }
+        __syncthreads();                               // (the reduction scratch is the image region)
+    }
     // guard rows stay zero for the whole kernel
     if (rr == 0) {
         *(uint4*)(Xi + 0 * PITCH + cc * 16) = make_uint4(0, 0, 0, 0);
@@ -479,6 +550,7 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
             const int64_t winc = ok ? win : 0;                     // clamped: loads are unconditional
             const int wpos = ok ? wp - 1 : 0;
             xg[q] = *(const GV*)((const unsigned char*)a.gin + ((winc * 12 + wpos) * 64 + cc * EPC) * (int64_t)sizeof(GV) / EPC);
+            if constexpr (BN2) xr2[q] = *(const uint4*)((const T*)a.r2 + (winc * 12 + wpos) * 64 + cc * EPC);
             const float* xw = a.x + winc * 12;
             xr[q][0] = xw[wpos > 0 ? wpos - 1 : 0];
             xr[q][1] = xw[wpos];
@@ -505,6 +577,24 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
                 uint4 xv;
                 if constexpr (G8) xv = f8_chunk5_to_bf16(xg[q], gd);
                 else xv = xg[q];
+                if constexpr (BN2) {
+                    float gv[EPC], rv[EPC];
+                    D::unpack(xv, gv);
+                    D::unpack(xr2[q], rv);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) gv[e] = rv[e] > 0.f ? fmaf(c2a[e], gv[e], fmaf(c2b[e], rv[e], c2z[e])) : 0.f;
+                    xv = D::pack(gv);
+                    if (ok) {
+                        *(uint4*)((T*)const_cast<void*>(a.gin) + ((win0 + nl) * 12 + wpos) * 64 + cc * EPC) = xv;      // (each element belongs to one thread of one block)
+                        D::unpack(xv, gv);                                                            // the sums are of the values as stored
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            cs_all[e] += gv[e];
+                            cs_first[e] += wpos == 0 ? gv[e] : 0.f;
+                            cs_last[e] += wpos == 11 ? gv[e] : 0.f;
+                        }
+                    }
+                }
                 if (!ok) { xv = make_uint4(0, 0, 0, 0); yv = make_uint4(0, 0, 0, 0); }
                 if (ir < CONV_WG_IMG) {
                     *(uint4*)(Xi + (ir + 1) * PITCH + cc * 16) = xv;
@@ -541,6 +631,24 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
             slab[p * 192 + q] = acc[tap][g];
         }
     }
+    if constexpr (BN2) {
+        // column sums of the transformed gradient (all positions / position 0 / position 11): the row slots folded in a fixed order
+        float* red = (float*)smem;                         // [3][RPP][64]  (the strip loop ended with a barrier)
+        static_assert(2 * ROWS * PITCH >= 3 * RPP * 64 * 4, "the column-sum reduction reuses the image region");
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            red[(0 * RPP + rr) * 64 + cc * EPC + e] = cs_all[e];
+            red[(1 * RPP + rr) * 64 + cc * EPC + e] = cs_first[e];
+            red[(2 * RPP + rr) * 64 + cc * EPC + e] = cs_last[e];
+        }
+        __syncthreads();
+        if (tid < 192) {
+            const int which = tid >> 6, c = tid & 63;
+            float s = 0.f;
+            for (int q = 0; q < RPP; ++q) s += red[(which * RPP + q) * 64 + c];
+            a.gcols3[((int64_t)blockIdx.x * 3 + which) * 64 + c] = s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -558,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(ConvArgs a) {
 // no output tile in LDS.  Replaces conv2_strip_kernel<T, 1> + conv1_bwd_kernel: 258 MB less written and 266 MB less read per
 // step at 167,936 windows.
 // ------------------------------------------------------------------------------------------
-template <typename T, bool G8 = false>
+template <typename T, bool G8 = false, bool ROWS = false>
 __global__ __launch_bounds__(256, 2) void conv2_dgrad_conv1_kernel(ConvArgs a) {
     static_assert(!G8 || sizeof(T) == 2, "e5m2 gradients are expanded into a bf16 image");
     using GV = std::conditional_t<G8, uint2, uint4>;
@@ -589,7 +697,17 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_conv1_kernel(ConvArgs a) {
     // this lane's conv1 channel
     const int ch1 = ft * 32 + r;
     const float w0 = a.w1[ch1 * 9 + 3], w1 = a.w1[ch1 * 9 + 4], w2 = a.w1[ch1 * 9 + 5], b1 = a.b1[ch1];
-    const float ca = a.coef[ch1], cb = a.coef[64 + ch1], cz = a.coef[128 + ch1];
+    float ca, cb, cz;
+    if constexpr (ROWS) {
+        // small batches: BatchNorm1's backward coefficients from conv2_wgrad_finish_kernel's rows, here (no finalize launch in between)
+        __shared__ float ca_s[64], cb_s[64], cz_s[64];
+        conv_bn_bwd_coef(a.rows1, a.rows1_nr, 1, a.stats1, (double)a.n_windows * 12, ca_s, cb_s, cz_s, (double (*)[4][64])smem, blockIdx.x == 0,
+                         a.dgamma1, a.dbeta1);
+        ca = ca_s[ch1]; cb = cb_s[ch1]; cz = cz_s[ch1];
+        __syncthreads();                               // (the reduction scratch is the image region; the weights come after it)
+    } else {
+        ca = a.coef[ch1]; cb = a.coef[64 + ch1]; cz = a.coef[128 + ch1];
+    }
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 
     auto load_x = [&](int64_t strip) {

@@ -561,38 +561,45 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
 //     S1[c] = sum_{n,p} g_v1[n][p][c]           = sum_{o,tap} W2[o][c][tap] G[o][tap]
 //     S2[c] = sum_{n,p} g_v1[n][p][c] r1[n][p][c] = sum_{o,tap} W2[o][c][tap] P[o][tap][c]
 // (g_v1 = conv2's data gradient; W2 rounded as the data-gradient kernel's operand is).  gcols: nr partial rows [768] of the column
-// sums of g seen as [N][q * 64 + o] -- the bias-gradient rows fc1's data-gradient launch wrote, or colsum_kernel's.
+// sums of g seen as [N][q * 64 + o] -- the bias-gradient rows fc1's data-gradient launch wrote, or colsum_kernel's; or (gcols3, small
+// batches) nr rows [3][64] of the sums over all positions / position 0 / position 11 from conv2_wgrad_kernel<T, false, true>, in which case
+// conv2's bias gradient db2 is written here too.
 // grid CONV2_FINISH_ROWS = 64 blocks (one output channel each) x 256 threads; out_rows[64][2][64] in bn_bwd_finalize_kernel's layout.
 // ------------------------------------------------------------------------------------
 #define CONV2_FINISH_ROWS 64
 template <typename T>
 __global__ __launch_bounds__(256) void conv2_wgrad_finish_kernel(const float* __restrict__ slabs, int S, const float* __restrict__ gcols, int nr,
                                                                  const float* __restrict__ W2, const float* __restrict__ stats1,
-                                                                 float* __restrict__ dW2, float* __restrict__ out_rows) {
+                                                                 float* __restrict__ dW2, float* __restrict__ out_rows,
+                                                                 const float* __restrict__ gcols3 = nullptr, float* __restrict__ db2 = nullptr) {
     using D = DT<T>;
     __shared__ double part[21][12];
     __shared__ float Gs[3];
     __shared__ float red[2][3][64];
     const int tid = threadIdx.x, o = blockIdx.x;
-    if (tid < 252) {
-        const int q = tid % 12, ls = tid / 12;
+    const int ncol = gcols3 ? 3 : 12;
+    if (tid < 21 * ncol) {
+        const int q = tid % ncol, ls = tid / ncol;
         double s = 0;
-        for (int rw = ls; rw < nr; rw += 21) s += (double)gcols[(int64_t)rw * 768 + q * 64 + o];
+        if (gcols3) { for (int rw = ls; rw < nr; rw += 21) s += (double)gcols3[(int64_t)rw * 192 + q * 64 + o]; }
+        else { for (int rw = ls; rw < nr; rw += 21) s += (double)gcols[(int64_t)rw * 768 + q * 64 + o]; }
         part[ls][q] = s;
     }
     __syncthreads();
-    if (tid < 12) {
+    if (tid < ncol) {
         double s = 0;
         for (int ls = 0; ls < 21; ++ls) s += part[ls][tid];
         part[0][tid] = s;                              // (column tid: only this thread read it)
     }
     __syncthreads();
     if (tid == 0) {
-        double all = 0;
-        for (int q = 0; q < 12; ++q) all += part[0][q];
-        Gs[0] = (float)(all - part[0][0]);
+        double all = 0, first, last;
+        if (gcols3) { all = part[0][0]; first = part[0][1]; last = part[0][2]; }
+        else { for (int q = 0; q < 12; ++q) all += part[0][q]; first = part[0][0]; last = part[0][11]; }
+        Gs[0] = (float)(all - first);
         Gs[1] = (float)all;
-        Gs[2] = (float)(all - part[0][11]);
+        Gs[2] = (float)(all - last);
+        if (db2 != nullptr) db2[o] = (float)all;
     }
     __syncthreads();
     if (tid < 192) {
