@@ -180,7 +180,7 @@ def test_register_stationary_gemm_kernel_has_no_spills():
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh"), "gemm_wsd?(16n?|8)?_kernel"], capture_output=True, text=True,
                          check=True).stdout
     lines = [l for l in out.splitlines() if "gemm_ws" in l]
-    assert len(lines) >= 9, out
+    assert len(lines) >= 8, out          # (ws16, ws16n, wsd16<0|1>, ws8<512|768>, wsd8<0|1, false>)
     for l in lines:
         assert re.search(r"spill\s+0\s+scratch\s+0\b", l), l
 
