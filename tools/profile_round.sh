@@ -8,18 +8,11 @@ O=gpurun_out
 # the plain bench line first: behind the four profiled runs the chip is warm and the same build reads 2-4 % slower
 timeout -k 10 400 python bench.py "$@" > $O/${R}_bench.log 2>&1; tail -1 $O/${R}_bench.log > $O/${R}_bench.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/${R}_stats -- python3 bench.py --main_only --steps 10 --warmup 3 "$@" > $O/${R}_stats.log 2>&1 || exit 1
-# counter passes on ONE stream: a kernel's HBM bytes and matrix-pipe cycles are read over its own execution, which must not overlap another's
-export CPNATIVE_AUX_STREAM=0
+# counter passes (one stream, the default: a kernel's HBM bytes and matrix-pipe cycles are read over its own execution)
 for Cn in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 280 rocprofv3 --pmc $Cn --kernel-trace -d $O/${R}_$Cn -- python3 bench.py --main_only --steps 4 --warmup 2 "$@" > $O/${R}_$Cn.log 2>&1 || exit 1
 done
 timeout -k 10 280 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/${R}_SQ -- python3 bench.py --main_only --steps 4 --warmup 2 "$@" > $O/${R}_SQ.log 2>&1 || echo "SQ pass failed (see $O/${R}_SQ.log)"
-# one-stream kernel trace (CPNATIVE_AUX_STREAM=0): the kernel-alone durations that bench.py's roofline block is held to
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/${R}_serial -- python3 bench.py --main_only --steps 10 --warmup 3 "$@" > $O/${R}_serial.log 2>&1 || echo "serial trace failed"
-unset CPNATIVE_AUX_STREAM
-python tools/parse_profile.py stats $O/${R}_serial $O/${R}_serial_kernel_stats.csv || true
-python tools/step_kernels.py $O/${R}_serial > $O/${R}_serial_step_kernels.txt || true
-rm -rf $O/${R}_serial
 python tools/parse_profile.py stats $O/${R}_stats $O/${R}_kernel_stats.csv
 python tools/step_kernels.py $O/${R}_stats > $O/${R}_step_kernels.txt
 python tools/step_kernels.py $O/${R}_stats --timeline > $O/${R}_step_timeline.txt
