@@ -1808,11 +1808,13 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // gradient above (round 3 and the tools build: a first pass of the same product, proj_dgrad_kernel<0>)
             int nr = PROJ_FINISH_ROWS;
             const float* pp = partials;
+#ifdef CP_VARIANTS
             if (!proj_alg) {
                 CK(launch_proj_dgrad<0>(a, st, &drows));
                 nr = drows;
                 pp = pre(nr, 2 * 512);
             }
+#endif
             if (int e = bwd_finalize(pp, nr, (double)N, 8, 512, 1, "bn_bwd_finalize_kernel(fc7, projection)")) return e;
             a.coef = coef; a.coef_mod = 512;
             CK(launch_proj_dgrad<1>(a, st, &drows));

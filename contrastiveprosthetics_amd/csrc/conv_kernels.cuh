@@ -820,82 +820,3 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_conv1_kernel(ConvArgs a) {
         a.partials[((int64_t)blockIdx.x * 4 + k) * 64 + c] = s;
     }
 }
-
-// ------------------------------------------------------------------------------------------
-// conv1 backward: BN1+ReLU backward fused with conv1's dW/db; r1 recomputed, nothing else read
-// but g_v1.  partials[block][4][64]: dW tap0..2, db.
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 3) void conv1_bwd_kernel(const T* __restrict__ g, const float* __restrict__ x,
-                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                        const float* __restrict__ coef, float* __restrict__ partials,
-                                                        int64_t rows) {
-    using Gm = ConvGeo<T>;
-    using D = DT<T>;
-    constexpr int EPC = Gm::EPC, CPR = Gm::CPR, RPP = Gm::RPP, C = 64;
-    __shared__ float red[4][RPP][64];
-    const int tid = threadIdx.x, cc = tid % CPR, rr = tid / CPR;
-    float wt[EPC][3], bs[EPC];
-    f32x2_t ca[EPC / 2], cb[EPC / 2], cz[EPC / 2], acc[4][EPC / 2];       // channel pairs (packed f32 arithmetic)
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        const int c = cc * EPC + e;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) wt[e][k] = w[c * 9 + 3 + k];
-        bs[e] = bias[c];
-        ca[e / 2][e & 1] = coef[c];
-        cb[e / 2][e & 1] = coef[C + c];
-        cz[e / 2][e & 1] = coef[2 * C + c];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int q = 0; q < EPC / 2; ++q) acc[k][q] = (f32x2_t){0.f, 0.f};
-    // one window per thread and pass (as conv1_stats_kernel): three 16-byte loads of x, twelve independent 16-byte loads of
-    // the gradient, positions unrolled -- no per-row divide, no clamped neighbour loads (82 -> 56 us at 167,936 windows)
-    const int64_t nwin = rows / 12;
-    for (int64_t win = (int64_t)blockIdx.x * RPP + rr; win < nwin; win += (int64_t)gridDim.x * RPP) {
-        float xv[12];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const float4 t = *(const float4*)(x + win * 12 + 4 * q);
-            xv[4 * q] = t.x; xv[4 * q + 1] = t.y; xv[4 * q + 2] = t.z; xv[4 * q + 3] = t.w;
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-        uint4 gq[6];                                               // six loads in flight per thread, twice
-#pragma unroll
-        for (int u = 0; u < 6; ++u) gq[u] = *(const uint4*)(g + (win * 12 + half * 6 + u) * C + cc * EPC);
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int wp = half * 6 + u;
-            const float xm = wp > 0 ? xv[wp - 1] : 0.f, x0 = xv[wp], xp = wp < 11 ? xv[wp + 1] : 0.f;
-            float gv[EPC], rv[EPC];
-            D::unpack(gq[u], gv);
-            conv1_chunk_vals<T>(xm, x0, xp, wt, bs, rv);
-            const f32x2_t xm2 = {xm, xm}, x02 = {x0, x0}, xp2 = {xp, xp};
-#pragma unroll
-            for (int q = 0; q < EPC / 2; ++q) {
-                const f32x2_t rp = {rv[2 * q], rv[2 * q + 1]}, gp = {gv[2 * q], gv[2 * q + 1]};
-                const f32x2_t t = __builtin_elementwise_fma(ca[q], gp, __builtin_elementwise_fma(cb[q], rp, cz[q]));
-                const f32x2_t gy = {rp.x > 0.f ? t.x : 0.f, rp.y > 0.f ? t.y : 0.f};
-                acc[0][q] = __builtin_elementwise_fma(gy, xm2, acc[0][q]);
-                acc[1][q] = __builtin_elementwise_fma(gy, x02, acc[1][q]);
-                acc[2][q] = __builtin_elementwise_fma(gy, xp2, acc[2][q]);
-                acc[3][q] += gy;
-            }
-        }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) red[k][rr][cc * EPC + e] = acc[k][e / 2][e & 1];
-    __syncthreads();
-    {
-        const int k = tid >> 6, c = tid & 63;
-        float s = 0.f;
-        for (int q = 0; q < RPP; ++q) s += red[k][q][c];
-        partials[((int64_t)blockIdx.x * 4 + k) * 64 + c] = s;
-    }
-}

@@ -509,7 +509,7 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ partials, in
 // sum weight-gradient slabs, undo the BN fold and scatter into the reference's layout.
 //   mode 0 (fc):   grad[p*Q + q]      = s[q]*P + t[q]*dbsum[p]
 //   mode 1 (fc1):  q = w*64 + c  ->   grad[p*768 + c*12 + w] = s[c]*P + t[c]*dbsum[p]
-//   mode 2 (conv2): q = tap*64 + i -> grad[((p*64+i)*3+1)*3+tap] = P  (+ zero the dead kernel rows)
+//   (conv2's slabs: conv2_wgrad_finish_kernel)
 //   mode 3 (transposed): grad[q*p_valid + p] = P   (slab rows are the operand that was padded)
 //   rows p >= p_valid are dropped (projection padded 16 -> 64)
 // ------------------------------------------------------------------------------------
@@ -536,19 +536,11 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int 
         for (; k < S; ++k) a0 += src[k * sstride];
         float acc = ((a0 + a1) + (a2 + a3)) * unscale;
         if (raw != nullptr) raw[i] = acc;              // un-fixed product g_y^T r, input of bn_bwd_sums_from_wgrad_kernel
-        if (mode == 2) {
-            const int tap = q >> 6, ii = q & 63;
-            const int base = (p * 64 + ii) * 9;
-            grad[base + 3 + tap] = acc;
-            grad[base + 0 + tap] = 0.f;
-            grad[base + 6 + tap] = 0.f;
-        } else {
-            int ch = q, dst = p * Q + q;
-            if (mode == 1) { ch = q & 63; dst = p * Q + ch * 12 + (q >> 6); }
-            if (mode == 3) dst = q * p_valid + p;
-            if (s != nullptr) acc = fmaf(s[ch], acc, t[ch] * dbsum[p]);
-            grad[dst] = acc;
-        }
+        int ch = q, dst = p * Q + q;
+        if (mode == 1) { ch = q & 63; dst = p * Q + ch * 12 + (q >> 6); }
+        if (mode == 3) dst = q * p_valid + p;
+        if (s != nullptr) acc = fmaf(s[ch], acc, t[ch] * dbsum[p]);
+        grad[dst] = acc;
     }
 }
 
