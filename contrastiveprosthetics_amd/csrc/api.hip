@@ -1216,6 +1216,9 @@ static int tap_gradient(const cp_config* c, int slot, const void* src, int64_t n
 }
 
 static inline void split_rows(int64_t M, int target_splits, int* splits, int64_t* rows_per_split);
+#ifndef CP_PROJ_SPLITS
+#define CP_PROJ_SPLITS 128                    // row splits of the projection's weight-gradient launch (tools: -DCP_PROJ_SPLITS=... for A/B runs)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // glove-angle class encoder
@@ -1738,7 +1741,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         const hipStream_t sw = aux.s();                 // (with dropout nothing waits for this weight gradient: second stream)
         ta.X = dz; ta.ldx = 64; ta.Y = Y; ta.ldy = 512; ta.slabs = aux.on ? slabs_b : slabs; ta.M = N; ta.P = 64; ta.Q = 512;
         int S;
-        split_rows(N, 128, &S, &ta.rows_per_split);
+        split_rows(N, CP_PROJ_SPLITS, &S, &ta.rows_per_split);
 #ifdef CP_VARIANTS
         const bool fused_u8 = drop && !g_var.materialize_u8;
         const bool proj_alg = fuse_ok && drop && sizeof(T) == 2 && !g_var.materialize_u8 && !g_var.no_proj_fused;
@@ -2034,7 +2037,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         ta.X = dz; ta.ldx = 64; ta.Y = base + w.act8[8]; ta.ldy = 512; ta.slabs = aux.on ? slabs_b : slabs; ta.M = N; ta.P = 64; ta.Q = 512;
         ta.y_exp = &fs->e[F8_T_ACT + 8];
         int S;
-        split_rows(N, 128, &S, &ta.rows_per_split);
+        split_rows(N, CP_PROJ_SPLITS, &S, &ta.rows_per_split);
         if (drop) {
             // (encoder_backward_t: one pass over r8 for the weight gradient AND fc7's BatchNorm-backward sums, on the critical path)
             ProjWgradArgs pa{};

@@ -261,7 +261,12 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
     __shared__ float xs[MODE == 0 ? 2 : 1][MODE == 0 ? CONV_WPB * 12 : 1];
     // CP_FP8 forward: scale of the e4m3 output and the largest scaled value this thread stored
     float out_scale = 1.f, out_max = 0.f;
-    if constexpr (MODE == 0 && sizeof(T) == 2) { if (a.out8 != nullptr) out_scale = f8_exp2i(*a.out_exp); }
+    if constexpr (MODE == 0 && sizeof(T) == 2) {
+        if (a.out8 != nullptr) {
+            out_scale = f8_exp2i(*a.out_exp);
+            __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);      // MODE.FP16_OVFL: the e4m3 conversions below saturate (fp8.cuh, f8_saturating_conversions)
+        }
+    }
     unsigned char* img = smem;
     unsigned char* Cs = smem;                      // aliases the image once the MFMAs are done
     unsigned char* Wl = smem + REGION;
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
                     // CP_FP8: the eight values of the chunk as e4m3 with the tensor's scale (v >= 0: clamp from above only)
                     float w8[EPC];
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) { w8[e] = v[e] * out_scale; out_max = fmaxf(out_max, w8[e]); w8[e] = fminf(w8[e], 448.f); }
+                    for (int e = 0; e < EPC; ++e) { w8[e] = v[e] * out_scale; out_max = fmaxf(out_max, w8[e]); }          // (v >= 0; the conversion saturates at 448)
                     int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[0], w8[1], 0, false), p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[4], w8[5], 0, false);
                     p0 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[2], w8[3], p0, true);
                     p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], p1, true);

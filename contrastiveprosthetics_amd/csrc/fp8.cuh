@@ -92,6 +92,10 @@ __device__ __forceinline__ uint32_t f8_pack4(float a, float b, float c, float d)
     return (uint32_t)p;
 }
 __device__ __forceinline__ float f8_clamp(float v) { return __builtin_amdgcn_fmed3f(v, -F8_E4M3_MAX, F8_E4M3_MAX); }
+// MODE.FP16_OVFL = 1 for the rest of the wave: v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32 then SATURATE finite values beyond the format's range
+// (1000 -> 448, 1e6 -> 57344; inf and NaN stay what they are) instead of returning NaN / inf, so the streaming passes and the data-gradient
+// epilogues convert without a v_med3_f32 per element (tools/fp8_sat_probe.hip, round 4; a new wave starts from the kernel descriptor's mode).
+__device__ __forceinline__ void f8_saturating_conversions() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }
 // Running maximum of a tensor: one candidate per wave, and the atomic only where it would raise the word -- thousands of waves end at
 // about the same time, and same-address atomics serialise in L2 (the first version, an unconditional atomicMax per wave, made the
 // 8-bit dropout pass 3x slower than the bf16 one).  The word is read past L1 (agent scope); a stale read costs one needless atomic.
@@ -455,6 +459,7 @@ __global__ __launch_bounds__(256) void bn_dropout_apply8_kernel(const uint8_t* _
                                                                 uint8_t* __restrict__ u, int64_t rows, int C, uint32_t thresh, uint32_t key,
                                                                 float inv_keep, const uint32_t* __restrict__ salt, Fp8State* __restrict__ st,
                                                                 int t_in, int t_out) {
+    f8_saturating_conversions();
     if (salt) key ^= *salt;
     const float din = f8_exp2i(-st->e[t_in]), dout = f8_exp2i(st->e[t_out]);
     const int cpr = C / 16, rpp = blockDim.x / cpr;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256) void bn_dropout_apply8_kernel(const uint8_t* _
             }
             amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
             amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
-            o[q] = f8_pack4(f8_clamp(v[0]), f8_clamp(v[1]), f8_clamp(v[2]), f8_clamp(v[3]));
+            o[q] = f8_pack4(v[0], v[1], v[2], v[3]);
         }
         *(uint4*)(u + m * C + f) = make_uint4(o[0], o[1], o[2], o[3]);
     };
@@ -648,6 +653,7 @@ __device__ __forceinline__ f32x4_t mx_mfma_g(const i32x8_t& w, const i32x8_t& g,
 #define WSD8_RT 32
 template <int MODE, bool OUT_BF16>
 __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
+    f8_saturating_conversions();                       // (the e5m2 stores of the epilogue carry no clamp)
     constexpr bool STATS = MODE == 1;
     constexpr int K = 512, KB = K / 128, RT = WSD8_RT, ST = RT / 16, NBUF = 4, AHEAD = NBUF - 1;
     constexpr int TILE_BYTES = RT * K, UPW = TILE_BYTES / 1024 / 4, CPR = K / 16, R_BYTES = RT * 64, RU = R_BYTES / 1024;
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
             } else {
                 amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
                 amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
-                d[ft] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+                d[ft] = f8_pack4_e5m2(y[0], y[1], y[2], y[3]);
                 f8_unpack4_e5m2(d[ft], y);
             }
 #pragma unroll
@@ -1094,6 +1100,7 @@ static inline hipError_t launch_gemm_tn8(const GemmTN8Args& a, hipStream_t st) {
 __global__ __launch_bounds__(256) void bn_relu_bwd8_kernel(uint8_t* __restrict__ g, const uint8_t* __restrict__ r, const float* __restrict__ coef,
                                                            float* __restrict__ partials, int64_t rows, int C, Fp8State* __restrict__ st,
                                                            int t_in, int t_r, int t_out) {
+    f8_saturating_conversions();
     extern __shared__ float dyn_red[];                  // [rpp][C]
     const int cpr = C / 16, rpp = 256 / cpr;
     const int tid = threadIdx.x, cc = tid % cpr, rr = tid / cpr;
@@ -1119,7 +1126,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd8_kernel(uint8_t* __restrict__
             for (int e = 0; e < 4; ++e) y[e] = rv[e] > 0.f ? fmaf(ca[4 * q + e], gv[e], fmaf(cb[4 * q + e], rv[e], cz[4 * q + e])) : 0.f;
             amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
             amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
-            o[q] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+            o[q] = f8_pack4_e5m2(y[0], y[1], y[2], y[3]);
             // column sums of the values AS STORED: the next layer's BatchNorm-backward sums are derived from this bias gradient and
             // from products of the stored tensor (bn_bwd_sums_from_wgrad_kernel), so the two must describe the same numbers
             f8_unpack4_e5m2(o[q], y);
@@ -1173,6 +1180,7 @@ struct Proj8Args {
 
 template <int PASS>
 __global__ __launch_bounds__(256, 2) void proj_dgrad8_kernel(Proj8Args a) {
+    f8_saturating_conversions();
     constexpr int RT = 32, ST = RT / 16, R_BYTES = RT * 64, F = 512;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 2 * R_BYTES];
 
@@ -1286,7 +1294,7 @@ __global__ __launch_bounds__(256, 2) void proj_dgrad8_kernel(Proj8Args a) {
                     y[3] = rv[3] > 0.f ? fmaf(ca.w, y[3], fmaf(cb.w, rv[3], cz.w)) : 0.f;
                     amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
                     amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
-                    d[ft] = f8_pack4_e5m2(f8_clamp5(y[0]), f8_clamp5(y[1]), f8_clamp5(y[2]), f8_clamp5(y[3]));
+                    d[ft] = f8_pack4_e5m2(y[0], y[1], y[2], y[3]);
                     f8_unpack4_e5m2(d[ft], y);                       // (column sums of the values as stored)
                 }
 #pragma unroll
