@@ -118,11 +118,15 @@ typedef struct cp_config {
     /* ---- test aid: while grad_tap is non-NULL, cp_encoder_backward copies every intermediate gradient into it (stream-ordered):
      * 9 slots of n_windows x 768 elements of the compute dtype; slot L = 2..8: dL/d(pre-activation of fc layer L-1), i.e. after
      * BatchNorm + ReLU backward, n_windows x 512; slot 1: dL/d(conv2 pre-activation), slot 0: dL/d(BN1 output), both
-     * n_windows x [12 positions][64 channels].  grad_tap_bytes = size of the buffer. */
+     * n_windows x [12 positions][64 channels].  grad_tap_bytes = size of the buffer.  (Slot 0 is no tensor of the step since round 4 --
+     * conv2's data gradient is consumed in the accumulators of conv2_dgrad_conv1_kernel -- so with a tap the call runs the stand-alone
+     * data-gradient kernel once more to fill it; CP_FP8: slots 0 and 1 hold the bf16 expansion of the e5m2 gradient.) */
     void* grad_tap;
     size_t grad_tap_bytes;
     /* ---- a second stream for the work of cp_encoder_backward that nothing in the step waits for (round 4; all three NULL = one
-     * stream).  The weight gradients of the layers behind a dropout (fc5..fc7, the projection) and conv2's are not on the step's
+     * stream, which is what contrastiveprosthetics_amd.engine passes by default: since the projection's and conv2's weight gradients
+     * carry BatchNorm-backward sums they are on the critical path, and with only fc5..fc7's left to float one stream measured
+     * faster -- DESIGN.md 7j).  The weight gradients of the layers behind a dropout (fc5..fc7) are not on the step's
      * critical path -- their BatchNorm-backward sums come from the data-gradient launches -- while ~40 latency-bound finaliser /
      * fold / reduction launches of the critical path leave most of the chip idle.  With aux_stream (a hipStream_t, ideally of
      * LOWER priority than `stream`) those weight-gradient launches and their slab reductions are enqueued there: aux_fork (a
