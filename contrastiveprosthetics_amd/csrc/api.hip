@@ -535,7 +535,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
     {
         ConvArgs ca{};
         ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0);
-        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = act(1); ca.partials = partials; ca.n_windows = N;
+        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = act(1); ca.partials = batch_stats ? partials : nullptr; ca.n_windows = N;
         const int g = conv_grid<T>(N);
         {
             ProfScope ps(CP_K_CONV2_FWD, st);
@@ -567,7 +567,12 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         a.A = A; a.lda = K; a.M = N; a.K = K;
         a.W = base + w.wfc[i]; a.F = 512;
         a.C = act(L); a.ldc = 512; a.bias = (float*)(base + w.bfc[i]); a.relu = 1;
+        // (evaluation with the running statistics: nobody reads the column sums -- the weight-stationary kernels then skip them; the
+        //  other dispatch targets ignore the distinction and write rows nobody reads)
+        a.partials = (batch_stats || sizeof(T) != 2 || dyn_tiles(c)) ? partials : nullptr;
+#ifdef CP_VARIANTS
         a.partials = partials;
+#endif
         int nrows = 0;
         {
             // (profiler kinds name ONE kernel each: K = 512 bf16 launches under the static schedule run gemm_ws_kernel)
@@ -694,7 +699,7 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
     {
         ConvArgs ca{};
         ca.x = x; ca.w1 = p->conv1_w; ca.b1 = p->conv1_b; ca.stats1 = stats(0);
-        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = nullptr; ca.partials = partials; ca.n_windows = N;
+        ca.wc = base + w.wc2_f; ca.bias2 = p->conv2_b; ca.out = nullptr; ca.partials = batch_stats ? partials : nullptr; ca.n_windows = N;
         ca.out8 = base + w.act8[1]; ca.out_exp = &fs->e[F8_T_ACT + 1]; ca.out_amax = &fs->amax[F8_T_ACT + 1];
         const int g = conv_grid<T>(N);
         {
@@ -728,7 +733,7 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
         }
         Ws8Args a{};
         a.A = A; a.W = base + w.wfc8[i]; a.wsc = base + w.wsc8[i]; a.bias = (float*)(base + w.bfc[i]);
-        a.C = base + w.act8[L]; a.partials = partials; a.amax = &fs->amax[F8_T_ACT + L]; a.M = N; a.F = 512;
+        a.C = base + w.act8[L]; a.partials = batch_stats ? partials : nullptr; a.amax = &fs->amax[F8_T_ACT + L]; a.M = N; a.F = 512;     // (nullptr: no column sums)
         int nrows = 0;
         {
             ProfScope ps(K == 512 ? CP_K_FC_FWD_WS : CP_K_FC_FWD, st);

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
     f32x2_t s1[EPC / 2], s2[EPC / 2];                // channel pairs (packed f32 adds / fmas)
 #pragma unroll
     for (int k = 0; k < EPC / 2; ++k) s1[k] = s2[k] = (f32x2_t){0.f, 0.f};
+    const bool want_sums = MODE != 0 || a.partials != nullptr || a.acc_out != nullptr;
 
     auto load_x = [&](int64_t strip) {
         const int64_t i = strip * (CONV_WPB * 12) + tid;
@@ -419,11 +420,13 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
             float v[EPC];
             D::unpack(ok ? c : make_uint4(0, 0, 0, 0), v);      // rows past the end count as zeros
             if constexpr (MODE == 0) {
+                if (want_sums) {                           // (uniform: evaluation with the running statistics has no reader for them)
 #pragma unroll
-                for (int k = 0; k < EPC / 2; ++k) {
-                    const f32x2_t vp = {v[2 * k], v[2 * k + 1]};
-                    s1[k] += vp;
-                    s2[k] = __builtin_elementwise_fma(vp, vp, s2[k]);
+                    for (int k = 0; k < EPC / 2; ++k) {
+                        const f32x2_t vp = {v[2 * k], v[2 * k + 1]};
+                        s1[k] += vp;
+                        s2[k] = __builtin_elementwise_fma(vp, vp, s2[k]);
+                    }
                 }
             } else {
                 float r1[EPC];
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv2_strip_kernel(ConvArgs a) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { red[(0 * RPP + rr) * 64 + cc * EPC + e] = s1[e / 2][e & 1]; red[(1 * RPP + rr) * 64 + cc * EPC + e] = s2[e / 2][e & 1]; }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < 128 && want_sums) {
         const int which = tid >> 6, c = tid & 63;
         float s = 0.f;
         for (int q = 0; q < RPP; ++q) s += red[(which * RPP + q) * 64 + c];

@@ -206,7 +206,7 @@ template <> struct Ws8Cfg<768> { static constexpr int RT = 32, NBUF = 4; };
 #ifndef WS8_WOVEN
 #define WS8_WOVEN 1
 #endif
-template <int K>
+template <int K, bool STATS = true>        // (STATS false: evaluation with the running statistics -- no column sums, gemm_ws.cuh)
 __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
     constexpr int KB = K / 128, RT = Ws8Cfg<K>::RT, ST = RT / 16, NBUF = Ws8Cfg<K>::NBUF, AHEAD = NBUF - 1;
     constexpr int TILE_BYTES = RT * K, UPW = TILE_BYTES / 1024 / 4, CPR = K / 16;
@@ -306,9 +306,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[e] = __builtin_amdgcn_fmed3f(old[ft][st][e], 0.f, F8_E4M3_MAX);
-                const float w = live ? v[e] : 0.f;
-                s1[ft * 4 + e] += w;
-                s2[ft * 4 + e] = fmaf(w, w, s2[ft * 4 + e]);
+                if constexpr (STATS) {
+                    const float w = live ? v[e] : 0.f;
+                    s1[ft * 4 + e] += w;
+                    s2[ft * 4 + e] = fmaf(w, w, s2[ft * 4 + e]);
+                }
             }
             amax = fmaxf(fmaxf(amax, old[ft][st][0]), old[ft][st][1]);
             amax = fmaxf(fmaxf(amax, old[ft][st][2]), old[ft][st][3]);
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
         r1[hh] = row16_fold8(v1, lane);
         r2[hh] = row16_fold8(v2, lane);
     }
-    if (s16 < 8) {
+    if (STATS && s16 < 8) {
         const int64_t prow = (int64_t)wkr * 8 + xcd;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -446,7 +448,8 @@ static inline hipError_t launch_gemm_ws8(const Ws8Args& a, hipStream_t st, int* 
     const int nwk = 32 / (a.F >> 8);
     const int64_t tiles = (a.M + Ws8Cfg<K>::RT - 1) / Ws8Cfg<K>::RT, workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
-    hipLaunchKernelGGL(gemm_ws8_kernel<K>, dim3(256), dim3(256), 0, st, a);
+    if (a.partials != nullptr) hipLaunchKernelGGL((gemm_ws8_kernel<K, true>), dim3(256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_ws8_kernel<K, false>), dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

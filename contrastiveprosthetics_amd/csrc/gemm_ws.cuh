@@ -102,6 +102,9 @@ __device__ __forceinline__ float row16_fold8(float (&v)[8], int lane) {
 #endif
 }
 
+// STATS = false (round 4): evaluation with the running statistics -- nobody reads the column sums, so the epilogue is max / convert / store
+// (1.5 instead of 3.5 vector instructions per output beside the matrix pipe).
+template <bool STATS = true>
 __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
     constexpr int K = WS_K, KB = K / 32, RPW = WS16_RT / 4, ST = WS16_ST;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WS16_TILE_BYTES + 768 * 4];
@@ -167,9 +170,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 asm("v_max_f32 %0, 0, %1" : "=v"(v[e]) : "v"(old.t[ft][st][e]));
-                const float w = live[st] ? v[e] : 0.f;
-                if (st == 0) { t1[o * 4 + e] = w; t2[o * 4 + e] = w * w; }
-                else { t1[o * 4 + e] += w; t2[o * 4 + e] = fmaf(w, w, t2[o * 4 + e]); }
+                if constexpr (STATS) {
+                    const float w = live[st] ? v[e] : 0.f;
+                    if (st == 0) { t1[o * 4 + e] = w; t2[o * 4 + e] = w * w; }
+                    else { t1[o * 4 + e] += w; t2[o * 4 + e] = fmaf(w, w, t2[o * 4 + e]); }
+                }
             }
             pk[o].x = cvt_pk_bf16<false>(v[0], v[1]);
             pk[o].y = cvt_pk_bf16<false>(v[2], v[3]);
@@ -178,9 +183,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
         const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
         const u32x4_t c = {sx[0], sy[0], sx[1], sy[1]};
         store_b128_settled(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.ldc + fp * 32) * 2, 0);
-        if (st == ST - 1) {
-            qs1[fp] += row16_fold8(t1, lane);
-            qs2[fp] += row16_fold8(t2, lane);
+        if constexpr (STATS) {
+            if (st == ST - 1) {
+                qs1[fp] += row16_fold8(t1, lane);
+                qs2[fp] += row16_fold8(t2, lane);
+            }
         }
     };
 
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
     }
     // the four 16-lane rows (q4) of the wave hold DIFFERENT features: no further reduction.  Lane (q4, s16), pair fp: value
     // s16 & 7 = o*4 + e  ->  feature f0 + fp*32 + o*16 + 4*q4 + e; lanes s16 < 8 write
-    if (s16 < 8) {
+    if (STATS && s16 < 8) {
         const int64_t prow = (int64_t)wkr * 8 + xcd;
 #pragma unroll
         for (int fp = 0; fp < 2; ++fp) {
@@ -309,6 +316,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16_kernel(GemmNTArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 #define WSN_RT 48
 #define WSN_TILE_BYTES (WSN_RT * WSK_ROWB)
+template <bool STATS = true>          // (false: evaluation with the running statistics, as gemm_ws16_kernel)
 __global__ __launch_bounds__(256, 1) void gemm_ws16n_kernel(GemmNTArgs a) {
     constexpr int K = WSK_K, KB = K / 32, RT = WSN_RT, ST = RT / 16, UPW = WSN_TILE_BYTES / 1024 / 4;
     static_assert(UPW <= KB, "one fetch unit per k block and wave");
@@ -375,9 +383,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16n_kernel(GemmNTArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 asm("v_max_f32 %0, 0, %1" : "=v"(v[e]) : "v"(old[o][st][e]));
-                const float w = live[st] ? v[e] : 0.f;
-                if (st == 0) { t1[o * 4 + e] = w; t2[o * 4 + e] = w * w; }
-                else { t1[o * 4 + e] += w; t2[o * 4 + e] = fmaf(w, w, t2[o * 4 + e]); }
+                if constexpr (STATS) {
+                    const float w = live[st] ? v[e] : 0.f;
+                    if (st == 0) { t1[o * 4 + e] = w; t2[o * 4 + e] = w * w; }
+                    else { t1[o * 4 + e] += w; t2[o * 4 + e] = fmaf(w, w, t2[o * 4 + e]); }
+                }
             }
             pk[o].x = cvt_pk_bf16<false>(v[0], v[1]);
             pk[o].y = cvt_pk_bf16<false>(v[2], v[3]);
@@ -386,9 +396,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16n_kernel(GemmNTArgs a) {
         const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
         const u32x4_t c = {sx[0], sy[0], sx[1], sy[1]};
         store_b128_settled(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.ldc) * 2, 0);
-        if (st == ST - 1) {
-            qs1 += row16_fold8(t1, lane);
-            qs2 += row16_fold8(t2, lane);
+        if constexpr (STATS) {
+            if (st == ST - 1) {
+                qs1 += row16_fold8(t1, lane);
+                qs2 += row16_fold8(t2, lane);
+            }
         }
     };
 
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws16n_kernel(GemmNTArgs a) {
         drain(accA, row0(ntile - 1));
     }
     // lane (q4, s16 < 8): value s16 = o*4 + e  ->  feature f0 + o*16 + 4*q4 + e
-    if (s16 < 8) {
+    if (STATS && s16 < 8) {
         const int64_t prow = (int64_t)wkr * 8 + xcd;
         const int f = f0 + (s16 >> 2) * 16 + 4 * q4 + (s16 & 3);
         a.partials[(prow * 2 + 0) * a.F + f] = qs1;
@@ -480,7 +492,8 @@ static inline hipError_t launch_gemm_ws16n(const GemmNTArgs& a, hipStream_t st, 
     const int nwk = 32 / (a.F >> 7);
     const int64_t tiles = (a.M + WSN_RT - 1) / WSN_RT, workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
-    hipLaunchKernelGGL(gemm_ws16n_kernel, dim3(256), dim3(256), 0, st, a);
+    if (a.partials != nullptr) hipLaunchKernelGGL(gemm_ws16n_kernel<true>, dim3(256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_ws16n_kernel<false>, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -956,6 +969,7 @@ static inline hipError_t launch_gemm_ws(const GemmNTArgs& a, hipStream_t st, int
     // (dbg 512 / option ws32: the v_mfma_f32_32x32x16_bf16 form instead of the 16x16x32 one)
     if (!m16) { hipLaunchKernelGGL((gemm_ws_kernel<EPI, WS_WAVES>), dim3(256), dim3(64 * WS_WAVES), 0, st, a); return hipGetLastError(); }
 #endif
-    hipLaunchKernelGGL(gemm_ws16_kernel, dim3(256), dim3(256), 0, st, a);
+    if (a.partials != nullptr) hipLaunchKernelGGL(gemm_ws16_kernel<true>, dim3(256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_ws16_kernel<false>, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
