@@ -10,8 +10,9 @@ constexpr int SV_T = 41;            // classes
 constexpr int SV_MPB = 8;           // subsets handled by one block (round 4: 32 made 2 x B blocks of ~40k serial instructions per thread --
                                     // 257 us for 64 subsets of 160 groups x 25 samples, most of the chip idle)
 constexpr int SV_VMAX = 64;         // samples per group supported
-constexpr int SV_VCHUNK = 6;        // logits tiles staged per pass: 6 x 41 rows keep 246 of the 256 threads busy
 constexpr int SV_TILE = SV_T * SV_T;
+
+struct __attribute__((packed, aligned(4))) SvF4 { float x, y, z, w; };
 
 struct SubsetVoteArgs {
     const float* logits;            // [B*V][41][41], group g = b*V + v
@@ -24,19 +25,20 @@ struct SubsetVoteArgs {
 };
 
 // grid (ceil(n_masks / SV_MPB), B), 256 threads, dynamic LDS = sv_lds_bytes(V).
-// Phase 1: the group's 41 x 41 logits tiles pass through LDS six samples at a time; thread (t, v) keeps
-// its row in registers and takes the arg-max over the member columns of each of the block's subsets
-// (first maximum wins) -> preds[m][v][t] (one byte each).
+// Phase 1: thread per (sample, row) of the group (V x 41 of them, a few per thread): its 41 logits come straight from global memory into
+// registers (41 independent loads; the tiles are L2-resident, every block of the group reads them) and the arg-max over the member
+// columns of each of the block's subsets (first maximum wins) goes to preds[m][v][t] (one byte each).  No logits tile in LDS (round 3 staged
+// four samples at a time through 27 KB of LDS: two blocks per CU, every LDS latency of phase 2 exposed -- 258 us for 64 subsets of
+// 160 x 25 samples; round 4: 19 KB, eight blocks per CU).
 // Phase 2: thread per (subset, row): running histogram of the V predictions, mode with ties to the
 // smallest class id (torch.mode), one hit per prefix length where the mode equals the row's label.
 static inline size_t sv_lds_bytes(int V) {
-    return (size_t)SV_VCHUNK * SV_TILE * 4 + (size_t)SV_MPB * V * SV_T + SV_MPB * 8 + (size_t)SV_MPB * V * 4 + 256 * SV_T;
+    return (size_t)SV_MPB * 8 + (size_t)SV_MPB * V * 4 + (size_t)SV_MPB * V * SV_T + 256 * SV_T;
 }
 
 __global__ __launch_bounds__(256) void subset_vote_kernel(SubsetVoteArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sv_smem[];
-    float* tile = (float*)sv_smem;                                                 // [SV_VCHUNK][SV_TILE]
-    unsigned long long* bits = (unsigned long long*)(sv_smem + SV_VCHUNK * SV_TILE * 4);   // [SV_MPB]
+    unsigned long long* bits = (unsigned long long*)sv_smem;                       // [SV_MPB]
     int* hits = (int*)(bits + SV_MPB);                                             // [SV_MPB][V]
     unsigned char* preds = (unsigned char*)(hits + SV_MPB * a.V);                  // [SV_MPB][V][41]
     unsigned char* hist = preds + (size_t)SV_MPB * a.V * SV_T;                     // [256][41]
@@ -53,34 +55,38 @@ __global__ __launch_bounds__(256) void subset_vote_kernel(SubsetVoteArgs a) {
         bits[tid] = w;
     }
     for (int i = tid; i < SV_MPB * V; i += 256) hits[i] = 0;
+    __syncthreads();
 
-    const int vs = tid / SV_T, t = tid % SV_T;              // (vs up to 6: threads 246..255 idle in phase 1)
-    for (int v0 = 0; v0 < V; v0 += SV_VCHUNK) {
-        __syncthreads();                                     // previous pass done with `tile` (and bits/hits written)
-        const int nv = (V - v0 < SV_VCHUNK) ? (V - v0) : SV_VCHUNK;
-        const float* src = a.logits + ((b * V + v0) * (int64_t)SV_TILE);
-        for (int i = tid; i < nv * SV_TILE; i += 256) tile[i] = src[i];
-        __syncthreads();
-        if (vs < nv) {
-            float x[SV_T];
+    const float* grp = a.logits + b * V * (int64_t)SV_TILE;
+    for (int item = tid; item < V * SV_T; item += 256) {
+        const int v = item / SV_T, t = item % SV_T;
+        // a row is 164 bytes at a 4-byte-aligned address: ten 16-byte loads (legal at 4-byte alignment in the unaligned access mode HSA runs in)
+        // and one dword -- 41 dword loads per lane, each touching 64 different cache lines per wave, were most of the kernel's time
+        float x[SV_T];
+        const SvF4* row4 = (const SvF4*)(grp + (int64_t)item * SV_T);
 #pragma unroll
-            for (int c = 0; c < SV_T; ++c) x[c] = tile[vs * SV_TILE + t * SV_T + c];
-            for (int m = 0; m < mcount; ++m) {
-                const unsigned long long w = bits[m];
-                int bi = 255;
-                if ((w >> t) & 1) {
-                    float best = 0.f;
-                    bi = -1;
+        for (int c4 = 0; c4 < SV_T / 4; ++c4) {
+            const SvF4 q = row4[c4];
+            x[4 * c4] = q.x; x[4 * c4 + 1] = q.y; x[4 * c4 + 2] = q.z; x[4 * c4 + 3] = q.w;
+        }
+        x[SV_T - 1] = grp[(int64_t)item * SV_T + SV_T - 1];
+        for (int m = 0; m < mcount; ++m) {
+            // the subset is the same for every lane: its 41 bits sit in two SGPRs and each column is a scalar branch, so only the
+            // MEMBER columns cost vector instructions (a compare and two selects)
+            const unsigned long long wv = bits[m];
+            const uint32_t wlo = __builtin_amdgcn_readfirstlane((uint32_t)wv), whi = __builtin_amdgcn_readfirstlane((uint32_t)(wv >> 32));
+            float best = -__builtin_inff();
+            int bi = -1;
 #pragma unroll
-                    for (int c = 0; c < SV_T; ++c) {
-                        const bool in = (w >> c) & 1;
-                        const bool take = in && (bi < 0 || x[c] > best);
-                        best = take ? x[c] : best;
-                        bi = take ? c : bi;
-                    }
+            for (int c = 0; c < SV_T; ++c) {
+                if ((c < 32 ? (wlo >> c) : (whi >> (c - 32))) & 1u) {
+                    const bool take = bi < 0 || x[c] > best;            // (first maximum wins; a NaN never replaces a number)
+                    best = take ? x[c] : best;
+                    bi = take ? c : bi;
                 }
-                preds[((size_t)m * V + (v0 + vs)) * SV_T + t] = (unsigned char)bi;
             }
+            const bool member = (t < 32 ? (wlo >> t) : (whi >> (t - 32))) & 1u;
+            preds[((size_t)m * V + v) * SV_T + t] = (unsigned char)(member ? bi : 255);
         }
     }
     __syncthreads();
