@@ -507,6 +507,16 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
             ra.eps = c->bn_eps;
             hipLaunchKernelGGL(bn_running_stats_kernel, dim3(CP_N_BN), dim3(512), 0, st, ra);
             CKL("bn_running_stats_kernel");
+            // ... so every BatchNorm fold of the pass (fc1..fc7 and the projection) can be made now, in one launch instead of eight between the GEMMs
+            FoldBnBatch fb{};
+            for (int i = 0; i < CP_N_FC; ++i) {
+                const int Lp = 1 + i;
+                fb.job[i] = FoldBnJob{p->fc_w[i], p->fc_b[i], stats(Lp) + 2 * kLayerC[Lp], stats(Lp) + 3 * kLayerC[Lp], base + w.wfc[i],
+                                      (float*)(base + w.bfc[i]), 512, fcK(i), i == 0 ? 1 : 0, 512};
+            }
+            fb.job[CP_N_FC] = FoldBnJob{p->last_w, nullptr, stats(8) + 2 * 512, stats(8) + 3 * 512, base + w.wlast, (float*)(base + w.blast), CP_D_E, 512, 0, 32};
+            hipLaunchKernelGGL((fold_linear_batch_kernel<T>), dim3(512, CP_N_FC + 1), dim3(256), 0, st, fb);
+            CKL("fold_linear_batch_kernel");
         }
         if (drop) {
             // the weights of the layers behind a dropout (fc5..fc7, projection) carry no BatchNorm fold: plain copies, all in one launch
@@ -557,7 +567,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
         }
-        if (!(drop && Lp >= 5)) {          // (the layers behind a dropout were copied by fold_copy_batch_kernel above)
+        if (!(drop && Lp >= 5) && batch_stats) {          // (the layers behind a dropout were copied by fold_copy_batch_kernel above; running statistics: folded up front)
             ProfScope ps(CP_K_FOLD, st);
             hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(512), dim3(256), 0, st, p->fc_w[i], p->fc_b[i], s, t,
                                (T*)(base + w.wfc[i]), (float*)(base + w.bfc[i]), 512, K, i == 0 ? 1 : 0);
@@ -607,7 +617,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
             CKL("bn_dropout_apply_kernel");
             A = u;
         }
-        if (!drop) {                       // (with dropout: copied by fold_copy_batch_kernel at the start of the pass)
+        if (!drop && batch_stats) {        // (with dropout: copied by fold_copy_batch_kernel at the start of the pass; running statistics: folded up front)
             ProfScope ps(CP_K_FOLD, st);
             hipLaunchKernelGGL((fold_linear_kernel<T>), dim3(32), dim3(256), 0, st, p->last_w, (const float*)nullptr, s, t,
                                (T*)(base + w.wlast), (float*)(base + w.blast), CP_D_E, 512, 0);
@@ -709,6 +719,18 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
         }
         if (int e = finalize(1, g, (double)R12, nullptr)) return e;      // (its sums are of the bf16-rounded values in true units)
     }
+    if (!batch_stats) {
+        // evaluation with the running statistics (no dropout): statistics and scale table are final, so the seven folds are one launch
+        ProfScope ps(CP_K_FOLD, st);
+        Fold8Batch fb{};
+        for (int i = 0; i < CP_N_FC; ++i) {
+            const int Lp = 1 + i;
+            fb.job[i] = Fold8Job{p->fc_w[i], p->fc_b[i], stats(Lp) + 2 * kLayerC[Lp], stats(Lp) + 3 * kLayerC[Lp], base + w.wfc8[i], base + w.wsc8[i],
+                                 (float*)(base + w.bfc[i]), fcK(i), i == 0 ? 1 : 0, F8_T_ACT + Lp, F8_T_ACT + 2 + i};
+        }
+        hipLaunchKernelGGL(fold_linear8_batch_kernel, dim3(512, CP_N_FC), dim3(256), 0, st, fb, (const Fp8State*)fs);
+        CKL("fold_linear8_batch_kernel");
+    }
     // fc1..fc7
     for (int i = 0; i < CP_N_FC; ++i) {
         const int L = 2 + i, Lp = L - 1, K = fcK(i);
@@ -725,7 +747,7 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
             CKL("bn_dropout_apply8_kernel");
             A = u; s = nullptr; t = nullptr;
         }
-        {
+        if (batch_stats) {                 // (running statistics: all seven folds were made in one launch before the loop)
             ProfScope ps(CP_K_FOLD, st);
             hipLaunchKernelGGL(fold_linear8_kernel, dim3(512), dim3(256), 0, st, p->fc_w[i], p->fc_b[i], s, t, base + w.wfc8[i], base + w.wsc8[i],
                                (float*)(base + w.bfc[i]), K, i == 0 ? 1 : 0, fs, t_in, F8_T_ACT + L);

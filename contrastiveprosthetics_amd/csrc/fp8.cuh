@@ -114,13 +114,13 @@ __device__ __forceinline__ void f8_atomic_amax(uint32_t* dst, float m) {
 //   scale operand;  out_b: [F] f32 bias in OUTPUT units (the accumulators start at it).  One block per output row.
 //   t_in / t_out: scale-table ids of the layer's input and output tensors (t_out < 0: eo = 0, f32 output).
 // ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fold_linear8_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                                           const float* __restrict__ s, const float* __restrict__ t,
-                                                           uint8_t* __restrict__ out_w, uint8_t* __restrict__ out_sc,
-                                                           float* __restrict__ out_b, int K, int mode, const Fp8State* __restrict__ st,
-                                                           int t_in, int t_out) {
+__device__ __forceinline__ void fold_linear8_row(const float* __restrict__ W, const float* __restrict__ b,
+                                                 const float* __restrict__ s, const float* __restrict__ t,
+                                                 uint8_t* __restrict__ out_w, uint8_t* __restrict__ out_sc,
+                                                 float* __restrict__ out_b, int K, int mode, const Fp8State* __restrict__ st,
+                                                 int t_in, int t_out, int j) {
     __shared__ float red[2][4];
-    const int j = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int ei = st->e[t_in], eo = t_out >= 0 ? st->e[t_out] : 0;
     float wv[3], acc = 0.f, am = 0.f;
 #pragma unroll
@@ -158,6 +158,20 @@ __global__ __launch_bounds__(256) void fold_linear8_kernel(const float* __restri
         out_sc[j] = (uint8_t)sb;
         out_b[j] = ((b ? b[j] : 0.f) + acc) * f8_exp2i(eo);
     }
+}
+__global__ __launch_bounds__(256) void fold_linear8_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                           const float* __restrict__ s, const float* __restrict__ t,
+                                                           uint8_t* __restrict__ out_w, uint8_t* __restrict__ out_sc,
+                                                           float* __restrict__ out_b, int K, int mode, const Fp8State* __restrict__ st,
+                                                           int t_in, int t_out) {
+    fold_linear8_row(W, b, s, t, out_w, out_sc, out_b, K, mode, st, t_in, t_out, blockIdx.x);
+}
+// the seven folds of an evaluation pass with the running statistics in one launch (kernels_misc.cuh, fold_linear_batch_kernel)
+struct Fold8Job { const float* W; const float* b; const float* s; const float* t; uint8_t* out_w; uint8_t* out_sc; float* out_b; int K, mode, t_in, t_out; };
+struct Fold8Batch { Fold8Job job[7]; };
+__global__ __launch_bounds__(256) void fold_linear8_batch_kernel(Fold8Batch fb, const Fp8State* __restrict__ st) {
+    const Fold8Job& jb = fb.job[blockIdx.y];
+    fold_linear8_row(jb.W, jb.b, jb.s, jb.t, jb.out_w, jb.out_sc, jb.out_b, jb.K, jb.mode, st, jb.t_in, jb.t_out, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

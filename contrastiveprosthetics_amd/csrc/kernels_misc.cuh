@@ -154,13 +154,13 @@ __global__ __launch_bounds__(512) void bn_running_stats_kernel(BnRunningAll a) {
 // out_b: [F] f32 (nullable when the layer has no bias and no fold),  s/t nullable -> plain copy.
 // ------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void fold_linear_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                                          const float* __restrict__ s, const float* __restrict__ t,
-                                                          T* __restrict__ out_w, float* __restrict__ out_b, int F, int K,
-                                                          int mode) {
+__device__ __forceinline__ void fold_linear_row(const float* __restrict__ W, const float* __restrict__ b,
+                                                const float* __restrict__ s, const float* __restrict__ t,
+                                                T* __restrict__ out_w, float* __restrict__ out_b, int F, int K,
+                                                int mode, int j) {
     using D = DT<T>;
     __shared__ float red[4];
-    const int j = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     float acc = 0.f;
     for (int k = tid; k < K; k += 256) {
         int kp = k, ch = k;
@@ -176,6 +176,23 @@ __global__ __launch_bounds__(256) void fold_linear_kernel(const float* __restric
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
     if (tid == 0 && out_b != nullptr && j < F) out_b[j] = (b ? b[j] : 0.f) + red[0] + red[1] + red[2] + red[3];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fold_linear_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                          const float* __restrict__ s, const float* __restrict__ t,
+                                                          T* __restrict__ out_w, float* __restrict__ out_b, int F, int K,
+                                                          int mode) {
+    fold_linear_row<T>(W, b, s, t, out_w, out_b, F, K, mode, blockIdx.x);
+}
+// every fold of a forward pass whose statistics exist up front (evaluation with the running statistics: bn_running_stats_kernel wrote all
+// nine tables) in ONE launch: blockIdx.y = job, blockIdx.x = output row (rows >= rows_out of a job: nothing to do)
+struct FoldBnJob { const float* W; const float* b; const float* s; const float* t; void* out_w; float* out_b; int F, K, mode, rows_out; };
+struct FoldBnBatch { FoldBnJob job[8]; };
+template <typename T>
+__global__ __launch_bounds__(256) void fold_linear_batch_kernel(FoldBnBatch fb) {
+    const FoldBnJob& jb = fb.job[blockIdx.y];
+    if ((int)blockIdx.x >= jb.rows_out) return;
+    fold_linear_row<T>(jb.W, jb.b, jb.s, jb.t, (T*)jb.out_w, jb.out_b, jb.F, jb.K, jb.mode, blockIdx.x);
 }
 
 // plain copies (no BatchNorm fold: the layers behind a dropout, whose input already is dropout(BN(.))) of several layers in ONE
