@@ -1175,9 +1175,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd8_kernel(uint8_t* __restrict__
 
 // ------------------------------------------------------------------------------------------------------------------------
 // The projection's data gradient behind fc7's dropout, 8-bit form of proj_dgrad_kernel (gemm_ws.cuh): g = mask (dz W) / (1 - p) is a
-// rank-16 product, computed TWICE.  PASS 0: the two BatchNorm-backward sums of g against the saved e4m3 activation R, nothing
-// stored.  PASS 1 (coefficients final): g again, r > 0 ? ca g + cb r + cz : 0, stored as e5m2 (F8_T_GRAD + 8), column sums = fc7's
-// bias gradient.  dz stays bf16 (16 live columns, [M][lda]); W = last_w^T in bf16 [512][K].
+// rank-16 product.  PASS 1 (coefficients final) is what the step launches: g, r > 0 ? ca g + cb r + cz : 0, stored as e5m2 (F8_T_GRAD + 8),
+// column sums = fc7's bias gradient.  PASS 0 -- the same product reduced to the two BatchNorm-backward sums against the saved e4m3
+// activation R, nothing stored -- was round 3's way to the coefficients and is no longer instantiated: the sums come with the projection's
+// weight gradient now (gemm_tn.cuh, proj_wgrad_sums_kernel<true>).  dz stays bf16 (16 live columns, [M][lda]); W = last_w^T in bf16 [512][K].
 // ------------------------------------------------------------------------------------------------------------------------
 struct Proj8Args {
     const bf16_t* A;        // dz [M][lda]
