@@ -48,17 +48,25 @@ def _step(dtype, groups, no_small, dp=0.0635):
     e.encoder_backward(x)
     torch.cuda.synchronize()
     act8 = e.debug_activation(8)                         # fc7's stored output relu(.)
+    masks = [e.debug_activation(l) > 0 for l in range(1, 9)]          # the ReLU masks of conv2, fc1..fc7
     grads = {k: e.grads.views[k].clone() for k in e.specs if k.startswith("emg_net.") or k.startswith("glove_net.easy.")}
     running = {k: v.clone() for k, v in e.running.items() if torch.is_tensor(v) and v.is_floating_point()}
-    return z, out.clone(), grads, running, act8
+    return z, out.clone(), grads, running, act8, masks
 
 
-@pytest.mark.parametrize("groups", [8, 33, 64])
+@pytest.mark.parametrize("groups", [5, 8, 32, 33, 64])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_small_batch_path_equals_large_batch_kernels(dtype, groups):
-    zs, outs, gs, rs, a8s = _step(dtype, groups, no_small=False)
-    zl, outl, gl, rl, a8l = _step(dtype, groups, no_small=True)
+    zs, outs, gs, rs, a8s, ms = _step(dtype, groups, no_small=False)
+    zl, outl, gl, rl, a8l, ml = _step(dtype, groups, no_small=True)
     f32 = dtype == "f32"
+    # f32: the two paths sum in different orders, so a pre-activation within a rounding step of zero can land on either side of it; the
+    # forward output moves by 1e-9, that element's ReLU mask flips and its whole gradient term (1 / rows of a column sum) is there or
+    # not (tools/relu_mask_flips.py, profiles/r04_relu_mask_flips.txt).  Where NO mask differs (5 and 32 groups with these seeds; the
+    # kernels are deterministic) every gradient must agree to f32 rounding; elsewhere only the tensors above every ReLU can be held to that.
+    n_flips = sum(int((u != v).sum()) for u, v in zip(ms, ml))
+    if f32 and groups in (5, 32):
+        assert n_flips == 0, n_flips
     zerr = float((zs - zl).abs().max() / zl.abs().max())
     assert zerr < (2e-5 if f32 else 3e-2), ("z", zerr)
     assert float(outs[0]) == pytest.approx(float(outl[0]), rel=2e-6 if f32 else 2e-4)
@@ -79,8 +87,11 @@ def test_small_batch_path_equals_large_batch_kernels(dtype, groups):
             # bf16: fc7's bias gradient at 8 groups is a sum of 328 values that two bf16 pipelines round differently (measured 2.5-4.8 %
             # across dropout masks; the round-4 hash draws other masks than round 3's, which read 3.x %)
             assert rel < (2e-5 if f32 else 7e-2), (k, rel)
+        elif f32 and n_flips == 0:
+            dev = float((a - b).abs().max() / b.abs().max())
+            assert dev < 2e-4 and rel < 2e-3, (k, dev, rel)          # (rel: bias / BatchNorm gradients are sums with heavy cancellation)
         elif f32:
-            assert rel < 3e-2 and cos > 0.9995, (k, rel, cos)       # (a handful of flipped elements in 328..2624 rows, see above)
+            assert rel < 3e-2 * max(1, n_flips) and cos > 0.999, (k, rel, cos, n_flips)       # (n_flips flipped elements in 205..2624 rows)
         else:
             assert rel < 0.35 and cos > 0.94, (k, rel, cos)
 
