@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 typedef uint16_t bf16_t;                                            // bf16 storage
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -12,6 +14,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CP_WAVE 64
+
+// f(integral_constant<int, 0>{}) .. f(integral_constant<int, N - 1>{}), in that order: a loop whose index is a constant expression
+// inside the body (template arguments, register-array indices, the paced epilogues' micro-op tables).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // The product library has NO process-wide switches: everything a call depends on travels in its cp_config (include/cpnative.h:
 // options, tile_schedule, the synchronised-BatchNorm hook, the gradient tap), so two engines in one process cannot see each other's

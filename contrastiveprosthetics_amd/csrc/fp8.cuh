@@ -207,6 +207,28 @@ __device__ __forceinline__ f32x4_t mx_mfma(const i32x8_t& w, const i32x8_t& x, c
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, x, c, 0, 0, FT, wscale, 0, 127);
 }
 
+// The same instruction as a volatile statement with the accumulator in VGPRs and the weights in AGPRs: it stays where it is written
+// (between the micro-operations of a paced epilogue) and the accumulators stay where the epilogue reads them.  The compiler's hazard
+// tables do not see inside: callers keep two wait states between a vector write of an operand and the statement, and eleven
+// between the statement and a vector read of its result.
+#define MX_MFMA_TEXT "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, "
+template <int FT>
+__device__ __forceinline__ void mx_mfma_pinned(const i32x8_t& w, const i32x8_t& x, f32x4_t& c, int wscale, int one) {
+    if constexpr (FT == 0) asm volatile(MX_MFMA_TEXT "%0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one));
+    if constexpr (FT == 1) asm volatile(MX_MFMA_TEXT "%0, %3, %4 op_sel:[1,0,0] op_sel_hi:[0,0,0]" : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one));
+    if constexpr (FT == 2) asm volatile(MX_MFMA_TEXT "%0, %3, %4 op_sel_hi:[1,0,0]" : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one));
+    if constexpr (FT == 3) asm volatile(MX_MFMA_TEXT "%0, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one));
+}
+// first k block: d = w x + c0 with c0 in registers of its own (the bias, fresh from LDS: no vector write in front of the statement;
+// the caller keeps c0 alive -- unwritten -- for seven states behind the statement: LLVM's SMFMA16x16ReadVgprVALUWar rule)
+template <int FT>
+__device__ __forceinline__ void mx_mfma_pinned0(const i32x8_t& w, const i32x8_t& x, f32x4_t& d, const f32x4_t& c0, int wscale, int one) {
+    if constexpr (FT == 0) asm volatile(MX_MFMA_TEXT "%5, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0));
+    if constexpr (FT == 1) asm volatile(MX_MFMA_TEXT "%5, %3, %4 op_sel:[1,0,0] op_sel_hi:[0,0,0]" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0));
+    if constexpr (FT == 2) asm volatile(MX_MFMA_TEXT "%5, %3, %4 op_sel_hi:[1,0,0]" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0));
+    if constexpr (FT == 3) asm volatile(MX_MFMA_TEXT "%5, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0));
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -217,24 +239,24 @@ template <int K> struct Ws8Cfg;
 template <> struct Ws8Cfg<512> { static constexpr int RT = 64, NBUF = 3; };
 template <> struct Ws8Cfg<768> { static constexpr int RT = 32, NBUF = 4; };
 
-#ifndef WS8_WOVEN
-#define WS8_WOVEN 1
-#endif
+constexpr int ws8_stores_after(int ng, int st_count, int g_last_fetch) {
+    int n = 0;
+    for (int st = 0; st < st_count; ++st) {
+        const int u = 19 * st + 18, nu = 19 * st_count;
+        int g = 0;
+        while (!(g * nu / ng <= u && u < (g + 1) * nu / ng)) ++g;
+        if (g >= g_last_fetch) ++n;
+    }
+    return n;
+}
 template <int K, bool STATS = true>        // (STATS false: evaluation with the running statistics -- no column sums, gemm_ws.cuh)
 __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
     constexpr int KB = K / 128, RT = Ws8Cfg<K>::RT, ST = RT / 16, NBUF = Ws8Cfg<K>::NBUF, AHEAD = NBUF - 1;
     constexpr int TILE_BYTES = RT * K, UPW = TILE_BYTES / 1024 / 4, CPR = K / 16;
-    // WOVEN: the previous tile's epilogue (ST parts) rides in the last ST k blocks of the k loop instead of behind it.  The bf16
-    // kernels measured that slower (a busy bf16 matrix pipe leaves the chip no power for vector work beside it); the 8-bit pipe
-    // runs at a quarter of the energy per product, the k loop is 2,048 cycles of MFMAs against ~2,000 of epilogue (SQ counters,
-    // profiles/r03_fp8_sq1.json: VALU active 45k cycles per wave, matrix pipe busy 42k), and an MFMA occupies the issue port for 8
-    // of its 32 cycles.
-    constexpr bool WOVEN = WS8_WOVEN != 0;
-    constexpr int EPI_KB0 = KB - ST;                           // first k block with an epilogue part
-    constexpr int KB_LF = (UPW - 1) / ST;                      // k block of the last fetch unit
-    // stores of one epilogue that are issued AFTER the step's last fetch unit
-    constexpr int SA = WOVEN ? (KB - (KB_LF > EPI_KB0 ? KB_LF : EPI_KB0) < ST ? KB - (KB_LF > EPI_KB0 ? KB_LF : EPI_KB0) : ST) : ST;
-    static_assert(EPI_KB0 >= 0, "one epilogue part per k block");
+    // stores of one paced epilogue (see epi_uop below) that are issued AFTER the step's last fetch unit: the store of sample tile st is
+    // micro-operation 19 st + 18 of NU = 19 ST, behind MFMA g with g NU / NG <= 19 st + 18 < (g + 1) NU / NG; the last fetch unit leads
+    // MFMA group 4 (UPW - 1)
+    constexpr int SA = ws8_stores_after(KB * ST * 4, ST, 4 * (UPW - 1));
     constexpr bool PF2 = ST < 4;         // few sample tiles: fragments of k block kb + 1 are requested in front of the MFMAs of kb (two sets)
     static_assert(UPW <= KB * ST, "one fetch unit per (k block, sample tile) slot at most");
     static_assert((AHEAD - 1) * UPW + AHEAD * ST <= 63, "vmcnt range");
@@ -301,6 +323,8 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
     float s1[16], s2[16], amax = 0.f;
 #pragma unroll
     for (int p = 0; p < 16; ++p) s1[p] = s2[p] = 0.f;
+    int scale_one = 127;                                                     // E8M0 2^0 for the sample rows, in a register of its own
+    asm volatile("" : "+v"(scale_one));
     const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * a.F), 0x00020000);
     const uint32_t c_lane = (uint32_t)(s16 * a.F + f0 + q4 * 16);
 
@@ -339,69 +363,136 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
         store_b128_settled(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.F), 0);
     };
 
-    auto load_frag = [&](const unsigned char* At, int kb, int st) -> i32x8_t {
-        const int c0 = kb * 8 + q4 * 2;
-        const i32x4_t lo = *(const i32x4_t*)(At + st * 16 * K + ((c0 ^ s16) << 4));
-        const i32x4_t hi = *(const i32x4_t*)(At + st * 16 * K + (((c0 + 1) ^ s16) << 4));
+    // fragment (kb, st) of a tile = row st*16 + s16, logical chunks kb*8 + q4*2 (+1), physical chunk = logical ^ s16: the XOR reaches
+    // bits 0-3 of the chunk index, of which kb owns bit 3 -- so a lane has four byte offsets (half h, parity of kb) and everything else
+    // is an immediate of the ds_read (32 v_add_u32 and as many registers of precomputed offsets per tile were spent on it before)
+    uint32_t fro[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pk = 0; pk < 2; ++pk) fro[h][pk] = (uint32_t)(s16 * K + ((pk ^ (s16 >> 3)) << 7) + (((q4 * 2 + h) ^ (s16 & 7)) << 4));
+    auto load_frag = [&](const unsigned char* const (&Ab)[2][2], int kb, int st) -> i32x8_t {
+        const int imm = (kb >> 1) * 256 + st * 16 * K;
+        const i32x4_t lo = *(const i32x4_t*)(Ab[0][kb & 1] + imm);
+        const i32x4_t hi = *(const i32x4_t*)(Ab[1][kb & 1] + imm);
         return (i32x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
-    // K loop of tile ti into acc; the fetches of tile ti + AHEAD go out along the way; WITH_EPI: the previous tile's epilogue runs
-    // behind the loop (gemm_ws16_kernel: vector instructions beside a busy matrix pipe cost more than their own time)
+    // The previous tile's epilogue as NU micro-operations, handed out evenly over the NG = KB * ST * 4 MFMAs of a k loop.  Per sample tile st:
+    // 16 x (clamp, sum, sum of squares of ONE output; with the odd ones the maximum and the conversion of the pair), two lane-swap
+    // pairs, the store.  tools/coissue8_probe.hip: behind each v_mfma_scale_f32_16x16x128 up to four vector instructions cost 1-4
+    // cycles of its 32, and the loop is bound by its fetches (34 us without any epilogue) -- what must not happen is what the compiler's
+    // own schedule did with the same instructions: runs of 12-16 bare MFMAs, then runs of 30 vector instructions.
+    // Placement is pinned by DATA: an empty `asm volatile` with a "+v" operand redefines a value where it stands, volatile statements
+    // keep their order, so whatever consumes the value cannot rise above the statement and whatever produces it cannot sink below.
+    // (__builtin_amdgcn_sched_barrier only binds the machine scheduler: with it alone the MFMAs of the last k block sank into the next
+    // step and the sums rose to its start.)  The accumulators live in VGPRs that way (the weights hold the AGPR half), so the epilogue
+    // reads them in place -- the compiler's own allocation kept them in AGPRs and copied 64 registers per tile.
+    constexpr int NG = KB * ST * 4, NU = ST * 19;
+    static_assert(NU <= 2 * NG, "at most two micro-operations behind one MFMA");
+    float vhold = 0.f, lim = F8_E4M3_MAX;
+    uint32_t dq[4] = {0u, 0u, 0u, 0u};
+    auto epi_uop = [&](f32x4_t (&old)[4][ST], auto uc, uint32_t s_old) {
+        constexpr int u = decltype(uc)::value, st = u / 19, r = u % 19;
+#ifdef WS8_NO_EPI
+        if constexpr (r == 0) asm volatile("" :: "v"(old[0][st]), "v"(old[1][st]), "v"(old[2][st]), "v"(old[3][st]));   // ablation build (tools only)
+        return;
+#endif
+        if constexpr (r < 16) {
+            // one output: clamp (ReLU and the format's range), column sum, column sum of squares; with the odd ones the running maximum of
+            // the pair and its conversion into one half of the feature tile's dword.  Whole statements: nothing of them moves, and
+            // hipcc pads nothing around them (an empty pin in front of a compiler-placed v_med3 cost one s_nop per output).
+            constexpr int ft = r / 4, e = r % 4, q = ft * 4 + e;
+            const float o = old[ft][st][e];
+            if constexpr ((e & 1) == 0) {
+                if constexpr (STATS) asm volatile("v_med3_f32 %0, %3, 0, %4\n\tv_add_f32 %1, %1, %0\n\tv_fmac_f32 %2, %0, %0" : "=&v"(vhold), "+v"(s1[q]), "+v"(s2[q]) : "v"(o), "v"(lim));
+                else asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(vhold) : "v"(o), "v"(lim));
+            } else {
+                const float op = old[ft][st][e - 1];
+                float v;
+                if constexpr (STATS) {
+                    if constexpr (e == 1) asm volatile("v_med3_f32 %0, %5, 0, %6\n\tv_add_f32 %1, %1, %0\n\tv_fmac_f32 %2, %0, %0\n\tv_max3_f32 %3, %3, %7, %5\n\tv_cvt_pk_fp8_f32 %4, %8, %0" : "=&v"(v), "+v"(s1[q]), "+v"(s2[q]), "+v"(amax), "+v"(dq[ft]) : "v"(o), "v"(lim), "v"(op), "v"(vhold));
+                    else asm volatile("v_med3_f32 %0, %5, 0, %6\n\tv_add_f32 %1, %1, %0\n\tv_fmac_f32 %2, %0, %0\n\tv_max3_f32 %3, %3, %7, %5\n\tv_cvt_pk_fp8_f32 %4, %8, %0 op_sel:[0,0,1]" : "=&v"(v), "+v"(s1[q]), "+v"(s2[q]), "+v"(amax), "+v"(dq[ft]) : "v"(o), "v"(lim), "v"(op), "v"(vhold));
+                } else {
+                    if constexpr (e == 1) asm volatile("v_med3_f32 %0, %3, 0, %4\n\tv_max3_f32 %1, %1, %5, %3\n\tv_cvt_pk_fp8_f32 %2, %6, %0" : "=&v"(v), "+v"(amax), "+v"(dq[ft]) : "v"(o), "v"(lim), "v"(op), "v"(vhold));
+                    else asm volatile("v_med3_f32 %0, %3, 0, %4\n\tv_max3_f32 %1, %1, %5, %3\n\tv_cvt_pk_fp8_f32 %2, %6, %0 op_sel:[0,0,1]" : "=&v"(v), "+v"(amax), "+v"(dq[ft]) : "v"(o), "v"(lim), "v"(op), "v"(vhold));
+                }
+            }
+        } else if constexpr (r == 16) {
+            asm volatile("s_nop 1" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));     // (a statement's v_cvt_pk wrote dq[3]: two states in front of the swaps)
+            { const auto x = __builtin_amdgcn_permlane32_swap(dq[0], dq[2], false, false); dq[0] = x[0]; dq[2] = x[1]; }
+            { const auto x = __builtin_amdgcn_permlane32_swap(dq[1], dq[3], false, false); dq[1] = x[0]; dq[3] = x[1]; }
+            asm volatile("" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));
+        } else if constexpr (r == 17) {
+            { const auto x = __builtin_amdgcn_permlane16_swap(dq[0], dq[1], false, false); dq[0] = x[0]; dq[1] = x[1]; }
+            { const auto x = __builtin_amdgcn_permlane16_swap(dq[2], dq[3], false, false); dq[2] = x[0]; dq[3] = x[1]; }
+            asm volatile("" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));
+        } else {
+            const u32x4_t c = {dq[0], dq[1], dq[2], dq[3]};
+#ifdef WS8_NO_STORE
+            asm volatile("" :: "v"(c));                                      // ablation build (tools only): everything but the store
+#else
+            store_b128_settled(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.F), 0);
+#endif
+        }
+    };
+
+    // K loop of tile ti into acc; the fetches of tile ti + AHEAD go out along the way; WITH_EPI: the previous tile's epilogue rides
+    // behind the MFMAs, micro-operations [g NU / NG, (g + 1) NU / NG) behind MFMA g; a group's fetch goes first in its group (the counted
+    // waits below need the order of fetches and stores: both are volatile statements)
     auto step = [&](f32x4_t (&acc)[4][ST], f32x4_t (&old)[4][ST], int ti, auto with_epi_tag, int64_t m_old) {
         constexpr bool WITH_EPI = decltype(with_epi_tag)::value;
         const int buf = ti % NBUF;
         const uint32_t next_soff = tile_soff(ti + AHEAD);
         const int nbuf = (ti + AHEAD) % NBUF;
+        const uint32_t s_old = (uint32_t)(m_old * a.F);
+        f32x4_t b0[4];
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            const float4 b4 = *(const float4*)(bias_s + f0 + ft * 16 + 4 * q4);
-            const f32x4_t b0 = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int st = 0; st < ST; ++st) acc[ft][st] = b0;
-        }
-        const unsigned char* At = smem + buf * TILE_BYTES + s16 * K;
+        for (int ft = 0; ft < 4; ++ft) b0[ft] = *(const f32x4_t*)(bias_s + f0 + ft * 16 + 4 * q4);
+        auto keep_b0 = [&]() { asm volatile("" :: "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3])); };
+        const unsigned char* const At[2][2] = {{smem + buf * TILE_BYTES + fro[0][0], smem + buf * TILE_BYTES + fro[0][1]},
+                                               {smem + buf * TILE_BYTES + fro[1][0], smem + buf * TILE_BYTES + fro[1][1]}};
         i32x8_t fa[PF2 ? 2 : 1][ST];
 #pragma unroll
         for (int st = 0; st < ST; ++st) fa[0][st] = load_frag(At, 0, st);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            constexpr int dummy = 0; (void)dummy;
-            if (PF2 && kb + 1 < KB) {
+        static_for<KB>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            if constexpr (PF2 && kb + 1 < KB) {
 #pragma unroll
                 for (int st = 0; st < ST; ++st) fa[(kb + 1) & 1][st] = load_frag(At, kb + 1, st);
             }
-#pragma unroll
-            for (int st = 0; st < ST; ++st) {
-                if (kb * ST + st < UPW) fetch_unit(next_soff, nbuf, kb * ST + st);
+            static_for<ST>([&](auto stc) {
+                constexpr int st = decltype(stc)::value;
+                if constexpr (kb * ST + st < UPW) fetch_unit(next_soff, nbuf, kb * ST + st);
                 const i32x8_t& x = fa[PF2 ? (kb & 1) : 0][st];
-                acc[0][st] = mx_mfma<0>(wreg[0][kb], x, acc[0][st], wscale);
-                acc[1][st] = mx_mfma<1>(wreg[1][kb], x, acc[1][st], wscale);
-                acc[2][st] = mx_mfma<2>(wreg[2][kb], x, acc[2][st], wscale);
-                acc[3][st] = mx_mfma<3>(wreg[3][kb], x, acc[3][st], wscale);
-                if (!PF2 && kb + 1 < KB) fa[0][st] = load_frag(At, kb + 1, st);
-            }
-            if constexpr (WITH_EPI && WOVEN)
-                if (kb >= EPI_KB0) {
-                    epi_st(old, kb - EPI_KB0, (uint32_t)(m_old * a.F), true);
-                    // (forcing one MFMA, then 3 or 5 of these vector instructions in its shadow with sched_group_barrier: 56.4 / 75.0 us
-                    //  against 57.5 on the same box -- as in bf16, the two pipes do not overlap for free)
-                }
-        }
-        if constexpr (WITH_EPI && !WOVEN) {
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t s_old = (uint32_t)(m_old * a.F);
-#pragma unroll
-            for (int st = 0; st < ST; ++st) epi_st(old, st, s_old, true);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // tile ti + 1 must have landed.  vmcnt retires in issue order (tools/vmcnt_order_probe.hip); younger than its fetches are the
+                static_for<4>([&](auto ftc) {
+                    constexpr int ft = decltype(ftc)::value, g = (kb * ST + st) * 4 + ft;
+                    if constexpr (kb == 0) mx_mfma_pinned0<ft>(wreg[ft][kb], x, acc[ft][st], b0[ft], wscale, scale_one);
+                    else mx_mfma_pinned<ft>(wreg[ft][kb], x, acc[ft][st], wscale, scale_one);
+                    if constexpr (WITH_EPI) {
+                        constexpr int u0 = g * NU / NG, u1 = (g + 1) * NU / NG;
+                        static_for<u1 - u0>([&](auto jc) { epi_uop(old, std::integral_constant<int, u0 + decltype(jc)::value>{}, s_old); });
+                    }
+                    if constexpr (ft == 3 && !PF2 && kb + 1 < KB) fa[0][st] = load_frag(At, kb + 1, st);
+                    // (an MFMA reads its C operand for several cycles: the bias registers of the first k block stay untouched by
+                    //  vector writes for at least seven states behind their last MFMA -- here: four more MFMAs)
+                    if constexpr (kb == 1 && st == 0 && ft == 3) keep_b0();
+                });
+            });
+        });
+        asm volatile("s_nop 11");                                            // (pinned MFMAs in front of whatever reads their results: 12 states)
+        // tile ti + 1 must have landed.  vmcnt retires in issue order (tools/vmcnt_order_probe.hip); younger than its LAST fetch are the
         // fetches of tiles ti + 2 .. ti + AHEAD and the stores of the epilogues that ran since: min(AHEAD, ti) epilogues, of the
         // oldest of which only the SA stores behind that step's last fetch count when all AHEAD are there
+#if defined(WS8_NO_STORE) || defined(WS8_NO_EPI)
+        constexpr int STC = 0, SAC = 0;                                      // ablation builds (tools only): no stores to count
+#else
+        constexpr int STC = ST, SAC = SA;
+#endif
         const int ne = ti < AHEAD ? ti : AHEAD;
         if (ne == 0) wait_vmcnt<(AHEAD - 1) * UPW>();
-        else if (ne < AHEAD) { if (ne == 1) wait_vmcnt<(AHEAD - 1) * UPW + ST>(); else wait_vmcnt<(AHEAD - 1) * UPW + 2 * ST>(); }
-        else wait_vmcnt<(AHEAD - 1) * UPW + (AHEAD - 1) * ST + SA>();
+        else if (ne < AHEAD) { if (ne == 1) wait_vmcnt<(AHEAD - 1) * UPW + STC>(); else wait_vmcnt<(AHEAD - 1) * UPW + 2 * STC>(); }
+        else wait_vmcnt<(AHEAD - 1) * UPW + (AHEAD - 1) * STC + SAC>();
         __builtin_amdgcn_s_barrier();
     };
     auto drain = [&](f32x4_t (&old)[4][ST], int64_t m_old) {
