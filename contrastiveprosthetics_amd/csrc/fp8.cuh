@@ -212,21 +212,35 @@ __device__ __forceinline__ f32x4_t mx_mfma(const i32x8_t& w, const i32x8_t& x, c
 // tables do not see inside: callers keep two wait states between a vector write of an operand and the statement, and eleven
 // between the statement and a vector read of its result.
 #define MX_MFMA_TEXT "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, "
-template <int FT>
+#define MX_SEL0 " op_sel_hi:[0,0,0]"
+#define MX_SEL1 " op_sel:[1,0,0] op_sel_hi:[0,0,0]"
+#define MX_SEL2 " op_sel_hi:[1,0,0]"
+#define MX_SEL3 " op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+// B5: the B operand (sample rows) is e5m2 (blgp:1: the data-gradient kernel's gradient rows); otherwise e4m3
+template <int FT, bool B5 = false>
 __device__ __forceinline__ void mx_mfma_pinned(const i32x8_t& w, const i32x8_t& x, f32x4_t& c, int wscale, int one) {
-    if constexpr (FT == 0) asm volatile(MX_MFMA_TEXT "%0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one));
-    if constexpr (FT == 1) asm volatile(MX_MFMA_TEXT "%0, %3, %4 op_sel:[1,0,0] op_sel_hi:[0,0,0]" : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one));
-    if constexpr (FT == 2) asm volatile(MX_MFMA_TEXT "%0, %3, %4 op_sel_hi:[1,0,0]" : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one));
-    if constexpr (FT == 3) asm volatile(MX_MFMA_TEXT "%0, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one));
+#define MX_ACC(SEL, FMT) asm volatile(MX_MFMA_TEXT "%0, %3, %4" SEL FMT : "+v"(c) : "a"(w), "v"(x), "v"(wscale), "v"(one))
+    if constexpr (!B5) {
+        if constexpr (FT == 0) MX_ACC(MX_SEL0, ""); if constexpr (FT == 1) MX_ACC(MX_SEL1, ""); if constexpr (FT == 2) MX_ACC(MX_SEL2, ""); if constexpr (FT == 3) MX_ACC(MX_SEL3, "");
+    } else {
+        if constexpr (FT == 0) MX_ACC(MX_SEL0, " blgp:1"); if constexpr (FT == 1) MX_ACC(MX_SEL1, " blgp:1"); if constexpr (FT == 2) MX_ACC(MX_SEL2, " blgp:1"); if constexpr (FT == 3) MX_ACC(MX_SEL3, " blgp:1");
+    }
+#undef MX_ACC
 }
 // first k block: d = w x + c0 with c0 in registers of its own (the bias, fresh from LDS: no vector write in front of the statement;
 // the caller keeps c0 alive -- unwritten -- for seven states behind the statement: LLVM's SMFMA16x16ReadVgprVALUWar rule)
 template <int FT>
 __device__ __forceinline__ void mx_mfma_pinned0(const i32x8_t& w, const i32x8_t& x, f32x4_t& d, const f32x4_t& c0, int wscale, int one) {
-    if constexpr (FT == 0) asm volatile(MX_MFMA_TEXT "%5, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0));
-    if constexpr (FT == 1) asm volatile(MX_MFMA_TEXT "%5, %3, %4 op_sel:[1,0,0] op_sel_hi:[0,0,0]" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0));
-    if constexpr (FT == 2) asm volatile(MX_MFMA_TEXT "%5, %3, %4 op_sel_hi:[1,0,0]" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0));
-    if constexpr (FT == 3) asm volatile(MX_MFMA_TEXT "%5, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0));
+#define MX_C0(SEL) asm volatile(MX_MFMA_TEXT "%5, %3, %4" SEL : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one), "v"(c0))
+    if constexpr (FT == 0) MX_C0(MX_SEL0); if constexpr (FT == 1) MX_C0(MX_SEL1); if constexpr (FT == 2) MX_C0(MX_SEL2); if constexpr (FT == 3) MX_C0(MX_SEL3);
+#undef MX_C0
+}
+// first k block of a product without bias: d = w x (C = the inline constant 0), e5m2 sample rows
+template <int FT>
+__device__ __forceinline__ void mx_mfma_pinned_z5(const i32x8_t& w, const i32x8_t& x, f32x4_t& d, int wscale, int one) {
+#define MX_Z(SEL) asm volatile(MX_MFMA_TEXT "0, %3, %4" SEL " blgp:1" : "=&v"(d) : "a"(w), "v"(x), "v"(wscale), "v"(one))
+    if constexpr (FT == 0) MX_Z(MX_SEL0); if constexpr (FT == 1) MX_Z(MX_SEL1); if constexpr (FT == 2) MX_Z(MX_SEL2); if constexpr (FT == 3) MX_Z(MX_SEL3);
+#undef MX_Z
 }
 
 template <int N>
@@ -239,13 +253,15 @@ template <int K> struct Ws8Cfg;
 template <> struct Ws8Cfg<512> { static constexpr int RT = 64, NBUF = 3; };
 template <> struct Ws8Cfg<768> { static constexpr int RT = 32, NBUF = 4; };
 
-constexpr int ws8_stores_after(int ng, int st_count, int g_last_fetch) {
+// paced epilogues: micro-operation u of NU = upst * st_count rides behind MFMA g with g NU / NG <= u < (g + 1) NU / NG; the store of sample
+// tile st is the last of its upst micro-operations.  How many of a step's stores are issued at or behind MFMA group g_from?
+constexpr int paced_stores_from(int ng, int st_count, int upst, int g_from) {
     int n = 0;
     for (int st = 0; st < st_count; ++st) {
-        const int u = 19 * st + 18, nu = 19 * st_count;
+        const int u = upst * st + upst - 1, nu = upst * st_count;
         int g = 0;
         while (!(g * nu / ng <= u && u < (g + 1) * nu / ng)) ++g;
-        if (g >= g_last_fetch) ++n;
+        if (g >= g_from) ++n;
     }
     return n;
 }
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws8_kernel(Ws8Args a) {
     // stores of one paced epilogue (see epi_uop below) that are issued AFTER the step's last fetch unit: the store of sample tile st is
     // micro-operation 19 st + 18 of NU = 19 ST, behind MFMA g with g NU / NG <= 19 st + 18 < (g + 1) NU / NG; the last fetch unit leads
     // MFMA group 4 (UPW - 1)
-    constexpr int SA = ws8_stores_after(KB * ST * 4, ST, 4 * (UPW - 1));
+    constexpr int SA = paced_stores_from(KB * ST * 4, ST, 19, 4 * (UPW - 1));
     constexpr bool PF2 = ST < 4;         // few sample tiles: fragments of k block kb + 1 are requested in front of the MFMAs of kb (two sets)
     static_assert(UPW <= KB * ST, "one fetch unit per (k block, sample tile) slot at most");
     static_assert((AHEAD - 1) * UPW + AHEAD * ST <= 63, "vmcnt range");
@@ -765,9 +781,10 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
     constexpr bool STATS = MODE == 1;
     constexpr int K = 512, KB = K / 128, RT = WSD8_RT, ST = RT / 16, NBUF = 4, AHEAD = NBUF - 1;
     constexpr int TILE_BYTES = RT * K, UPW = TILE_BYTES / 1024 / 4, CPR = K / 16, R_BYTES = RT * 64, RU = R_BYTES / 1024;
-    constexpr int R_OFF = NBUF * TILE_BYTES;
+    constexpr int R_OFF = NBUF * TILE_BYTES, RBUF = 3;
+    static_assert(!OUT_BF16, "the paced epilogue stores e5m2 (fc1's gradient into conv2 is e5m2 since round 4)");
     static_assert((AHEAD - 1) * UPW + AHEAD * (ST + RU) <= 63, "vmcnt range");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[R_OFF + 4 * 2 * R_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R_OFF + 4 * RBUF * R_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -844,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
         rsrc_l[k] = (uint32_t)(row * a.F + f0 + (((lane & 3) ^ ((row >> 2) & 3)) << 4));
     }
     auto fetch_r = [&](uint32_t tile_soff, int buf, int k) {
-        bufl16_lds(r_rsrc, rsrc_l[k], tile_soff, lds0 + R_OFF + (wave * 2 + buf) * R_BYTES + k * 1024);
+        bufl16_lds(r_rsrc, rsrc_l[k], tile_soff, lds0 + R_OFF + (wave * RBUF + buf) * R_BYTES + k * 1024);
     };
     auto row0 = [&](int ti) -> int64_t { return ((int64_t)ti * stride + first) * RT; };
     auto tile_soff = [&](int ti) -> uint32_t { return ti < ntile ? (uint32_t)(row0(ti) * K) : 0xFFF00000u; };
@@ -922,76 +939,156 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
     };
     constexpr int NST = OUT_BF16 ? 2 * ST : ST;                              // stores per epilogue
 
-    auto load_frag = [&](const unsigned char* At, int kb, int st) -> i32x8_t {
-        const int c0 = kb * 8 + q4 * 2;
-        const i32x4_t lo = *(const i32x4_t*)(At + st * 16 * K + ((c0 ^ s16) << 4));
-        const i32x4_t hi = *(const i32x4_t*)(At + st * 16 * K + (((c0 + 1) ^ s16) << 4));
+    // fragment reads on four lane bases + immediates (gemm_ws8_kernel)
+    uint32_t fro[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pk = 0; pk < 2; ++pk) fro[h][pk] = (uint32_t)(s16 * K + ((pk ^ (s16 >> 3)) << 7) + (((q4 * 2 + h) ^ (s16 & 7)) << 4));
+    auto load_frag = [&](const unsigned char* const (&Ab)[2][2], int kb, int st) -> i32x8_t {
+        const int imm = (kb >> 1) * 256 + st * 16 * K;
+        const i32x4_t lo = *(const i32x4_t*)(Ab[0][kb & 1] + imm);
+        const i32x4_t hi = *(const i32x4_t*)(Ab[1][kb & 1] + imm);
         return (i32x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
+    int scale_one = 127;
+    asm volatile("" : "+v"(scale_one));
+
+    // The previous tile's epilogue as micro-operations behind the MFMAs of the k loop (gemm_ws8_kernel has the mechanism: whole asm
+    // statements, accumulators in VGPRs).  Here the epilogue is 7 vector instructions per output against ONE MFMA per two outputs -- the
+    // launch is bound by its vector work -- so what pacing buys is the k loop's 32 x 32 matrix-pipe cycles underneath it, not the reverse.
+    // Per sample tile st: 8 x (pair of outputs: unpack the r / u pair | first output | second output | conversion + maximum | the pair as
+    // stored | its sums), two lane-swap pairs, the store: 51 micro-operations; NU = 102 behind NG = 32 MFMAs.
+    // The R sub-tile of the tile whose epilogue runs is read at the start of the step, so it is fetched one step EARLIER than round 3's
+    // (three buffers per wave): R(t + 1) goes out in step t, is waited for at the end of step t + 1 and read in step t + 2.
+    constexpr int NG = KB * ST * 4, UPST = 51, NU = ST * UPST;
+    // Two pairs of different feature tiles (A, B) alternate, statement by statement: hipcc pads one state between two asm statements
+    // when the second reads what the first wrote (84 s_nop per tile in the first build), and no statement here reads its predecessor's
+    // outputs -- two sets of temporaries and two running maxima.
+    f32x2_t rvp[2] = {{0.f, 0.f}, {0.f, 0.f}}, ysp[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float yy[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, amax2[2] = {0.f, 0.f};
+    uint32_t dq[4] = {0u, 0u, 0u, 0u};
+    auto epi_uop = [&](f32x4_t (&old)[4][ST], const uint32_t (&rr)[4][ST], auto uc, uint32_t s_old) {
+        constexpr int u = decltype(uc)::value, st = u / UPST, r = u % UPST;
+        if constexpr (r < 48) {
+            constexpr int blk = r / 12, ab = (r % 12) & 1, part = (r % 12) >> 1, ft = (blk >> 1) * 2 + ab, h = blk & 1, e0 = 2 * h, q = ft * 4 + e0;
+            if constexpr (part == 0) {                      // the pair's r / u bytes as f32
+                if constexpr (h == 0) asm volatile("v_cvt_pk_f32_fp8 %0, %1" : "=v"(rvp[ab]) : "v"(rr[ft][st]));
+                else asm volatile("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_1" : "=v"(rvp[ab]) : "v"(rr[ft][st]));
+            } else if constexpr (part < 3) {
+                // first / second output of the pair: y = BatchNorm + ReLU backward (MODE 0) or the dropout mask and 1 / (1 - p) (MODE 1)
+                constexpr int e = e0 + part - 1;
+                const float o = old[ft][st][e], rv = rvp[ab][part - 1];
+                if constexpr (!STATS) {
+                    const float ca = ((const float*)&cfa[ft])[e], cb = ((const float*)&cfb[ft])[e], cz = ((const float*)&cfz[ft])[e];
+                    asm volatile("v_fma_f32 %0, %1, %2, %3\n\tv_fma_f32 %0, %4, %5, %0\n\tv_cmp_lt_f32 vcc, 0, %2\n\tv_cndmask_b32 %0, 0, %0, vcc"
+                                 : "=&v"(yy[ab][part - 1]) : "v"(cb), "v"(rv), "v"(cz), "v"(ca), "v"(o) : "vcc");
+                } else {
+                    asm volatile("v_mul_f32 %0, %1, %2\n\tv_cmp_neq_f32 vcc, 0, %3\n\tv_cndmask_b32 %0, 0, %0, vcc" : "=&v"(yy[ab][part - 1]) : "v"(o), "v"(keep_so), "v"(rv) : "vcc");
+                }
+            } else if constexpr (part == 3) {               // the pair into its half of the feature tile's dword; the running maximum
+                if constexpr (h == 0) asm volatile("v_cvt_pk_bf8_f32 %0, %2, %3\n\tv_max3_f32 %1, %1, |%2|, |%3|" : "+v"(dq[ft]), "+v"(amax2[ab]) : "v"(yy[ab][0]), "v"(yy[ab][1]));
+                else asm volatile("v_cvt_pk_bf8_f32 %0, %2, %3 op_sel:[0,0,1]\n\tv_max3_f32 %1, %1, |%2|, |%3|" : "+v"(dq[ft]), "+v"(amax2[ab]) : "v"(yy[ab][0]), "v"(yy[ab][1]));
+            } else if constexpr (part == 4) {               // the pair AS STORED, back in f32
+                if constexpr (h == 0) asm volatile("v_cvt_pk_f32_bf8 %0, %1" : "=v"(ysp[ab]) : "v"(dq[ft]));
+                else asm volatile("v_cvt_pk_f32_bf8_sdwa %0, %1 src0_sel:WORD_1" : "=v"(ysp[ab]) : "v"(dq[ft]));
+            } else {                                        // the sums are of the values AS STORED
+                if constexpr (STATS) asm volatile("v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_fmac_f32 %2, %4, %6\n\tv_fmac_f32 %3, %5, %7"
+                                                  : "+v"(s1[q]), "+v"(s1[q + 1]), "+v"(s2[q]), "+v"(s2[q + 1]) : "v"(ysp[ab][0]), "v"(ysp[ab][1]), "v"(rvp[ab][0]), "v"(rvp[ab][1]));
+                else asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(s1[q]), "+v"(s1[q + 1]) : "v"(ysp[ab][0]), "v"(ysp[ab][1]));
+            }
+        } else if constexpr (r == 48) {
+            asm volatile("s_nop 1" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));     // (a statement's conversion wrote dq[3]: two states in front of the swaps)
+            { const auto x = __builtin_amdgcn_permlane32_swap(dq[0], dq[2], false, false); dq[0] = x[0]; dq[2] = x[1]; }
+            { const auto x = __builtin_amdgcn_permlane32_swap(dq[1], dq[3], false, false); dq[1] = x[0]; dq[3] = x[1]; }
+            asm volatile("" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));
+        } else if constexpr (r == 49) {
+            { const auto x = __builtin_amdgcn_permlane16_swap(dq[0], dq[1], false, false); dq[0] = x[0]; dq[1] = x[1]; }
+            { const auto x = __builtin_amdgcn_permlane16_swap(dq[2], dq[3], false, false); dq[2] = x[0]; dq[3] = x[1]; }
+            asm volatile("" : "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));
+        } else {
+            const u32x4_t c = {dq[0], dq[1], dq[2], dq[3]};
+            store_b128_settled(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.F), 0);
+        }
+    };
+    // stores of a step's epilogue at or behind the MFMA group of the step's last R fetch (slot UPW + RU - 1, four MFMAs per slot)
+    constexpr int SA = paced_stores_from(NG, ST, UPST, 4 * (UPW + RU - 1));
+    static_assert(UPW + RU <= KB * ST, "one fetch per (k block, sample tile) slot");
 
     auto step = [&](f32x4_t (&acc)[4][ST], f32x4_t (&old)[4][ST], int ti, auto with_epi_tag, int64_t m_old) {
         constexpr bool WITH_EPI = decltype(with_epi_tag)::value;
         const int buf = ti % NBUF;
         const uint32_t next_soff = tile_soff(ti + AHEAD);
         const int nbuf = (ti + AHEAD) % NBUF;
-        const uint32_t r_soff = (uint32_t)(row0(ti) * a.F);
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-            for (int st = 0; st < ST; ++st) acc[ft][st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const unsigned char* At = smem + buf * TILE_BYTES + s16 * K;
+        const uint32_t r_soff = ti + 1 < ntile ? (uint32_t)(row0(ti + 1) * a.F) : 0xFFF00000u;      // R(ti + 1)
+        const int rbuf = (ti + 1) % RBUF;
+        const uint32_t s_old = (uint32_t)(m_old * a.F);
+        const unsigned char* const At[2][2] = {{smem + buf * TILE_BYTES + fro[0][0], smem + buf * TILE_BYTES + fro[0][1]},
+                                               {smem + buf * TILE_BYTES + fro[1][0], smem + buf * TILE_BYTES + fro[1][1]}};
         i32x8_t fa[2][ST];
 #pragma unroll
         for (int st = 0; st < ST; ++st) fa[0][st] = load_frag(At, 0, st);
+        // the finished tile's r / u bytes: dword (ft, st) = features ft*16 + 4*q4 .. +3 of row st*16 + s16 (this wave's own sub-tile)
+        uint32_t rr[4][ST];
+        if constexpr (WITH_EPI) {
+            const unsigned char* Rw = smem + R_OFF + (wave * RBUF + (ti - 1) % RBUF) * R_BYTES;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            if (kb + 1 < KB) {
+            for (int st = 0; st < ST; ++st) {
+                const int row = st * 16 + s16, rsw = (row >> 2) & 3;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) rr[ft][st] = *(const uint32_t*)(Rw + row * 64 + ((ft ^ rsw) << 4) + 4 * q4);
+            }
+        }
+        static_for<KB>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            if constexpr (kb + 1 < KB) {
 #pragma unroll
                 for (int st = 0; st < ST; ++st) fa[(kb + 1) & 1][st] = load_frag(At, kb + 1, st);
             }
-#pragma unroll
-            for (int st = 0; st < ST; ++st) {
-                const int slot = kb * ST + st;
-                if (slot < UPW) fetch_unit(next_soff, nbuf, slot);
-                else if (slot < UPW + RU) fetch_r(r_soff, ti & 1, slot - UPW);
+            static_for<ST>([&](auto stc) {
+                constexpr int st = decltype(stc)::value, slot = kb * ST + st;
+                if constexpr (slot < UPW) fetch_unit(next_soff, nbuf, slot);
+                else if constexpr (slot < UPW + RU) fetch_r(r_soff, rbuf, slot - UPW);
                 const i32x8_t& x = fa[kb & 1][st];
-                acc[0][st] = mx_mfma_g<0>(wreg[0][kb], x, acc[0][st], wscale);
-                acc[1][st] = mx_mfma_g<1>(wreg[1][kb], x, acc[1][st], wscale);
-                acc[2][st] = mx_mfma_g<2>(wreg[2][kb], x, acc[2][st], wscale);
-                acc[3][st] = mx_mfma_g<3>(wreg[3][kb], x, acc[3][st], wscale);
-            }
-        }
-        // Everything this wave needs next has landed once its operations older than this tile's are done: the A fetches of tile
-        // ti + 1 and -- for the epilogue below -- the R sub-tile of tile ti - 1.  Younger than those: the previous epilogue's stores
-        // (none in the first two tiles), this tile's A fetches and R fetches.
-        const int ne = ti < 2 ? 0 : 1;
-        if (ti == 0) wait_vmcnt<(AHEAD - 1) * UPW + RU>();                      // (tiles 2, 3 and R(0) may fly; tile 1 has landed)
-        else if (ne == 0) wait_vmcnt<UPW + RU>();
-        else wait_vmcnt<NST + UPW + RU>();
-        if constexpr (WITH_EPI) {
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* Rw = smem + R_OFF + (wave * 2 + ((ti - 1) & 1)) * R_BYTES;
-            const uint32_t s_old = (uint32_t)(m_old * a.F);
-#pragma unroll
-            for (int st = 0; st < ST; ++st) epi_st(old, Rw, st, s_old, true, m_old);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                static_for<4>([&](auto ftc) {
+                    constexpr int ft = decltype(ftc)::value, g = slot * 4 + ft;
+                    if constexpr (kb == 0) mx_mfma_pinned_z5<ft>(wreg[ft][kb], x, acc[ft][st], wscale, scale_one);
+                    else mx_mfma_pinned<ft, true>(wreg[ft][kb], x, acc[ft][st], wscale, scale_one);
+                    if constexpr (WITH_EPI) {
+                        constexpr int u0 = g * NU / NG, u1 = (g + 1) * NU / NG;
+                        static_for<u1 - u0>([&](auto jc) { epi_uop(old, rr, std::integral_constant<int, u0 + decltype(jc)::value>{}, s_old); });
+                    }
+                });
+            });
+        });
+        asm volatile("s_nop 11");                                            // (pinned MFMAs in front of whatever reads their results: 12 states)
+        // What must have landed: the A fetches of tile ti + 1 (issued in step ti - 2) and R(ti) (issued in step ti - 1, its last piece
+        // at slot UPW + RU - 1).  Younger than that piece: the SA stores of step ti - 1 behind it (no epilogue in step 0) and everything of
+        // this step -- UPW + RU fetches and ST stores (none in step 0).  Step 0 waits for A(1) behind the prologue's A(2).
+        if (ti == 0) wait_vmcnt<2 * UPW + RU>();
+        else if (ti == 1) wait_vmcnt<UPW + RU + ST>();
+        else wait_vmcnt<UPW + RU + ST + SA>();
         __builtin_amdgcn_s_barrier();
     };
     auto drain = [&](f32x4_t (&old)[4][ST], int ti, int64_t m_old) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned char* Rw = smem + R_OFF + (wave * 2 + (ti & 1)) * R_BYTES;
+        const unsigned char* Rw = smem + R_OFF + (wave * RBUF + ti % RBUF) * R_BYTES;
         const uint32_t s_old = (uint32_t)(m_old * a.F);
 #pragma unroll
         for (int st = 0; st < ST; ++st) epi_st(old, Rw, st, s_old, m_old + st * 16 + s16 < a.M, m_old);
     };
 
     f32x4_t accA[4][ST], accB[4][ST];
+    // prologue: A(0), R(0), A(1), A(2) in this order: the wait below leaves A(1) and A(2) in flight
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t) {
         const uint32_t so_ = tile_soff(t);
 #pragma unroll
         for (int q = 0; q < UPW; ++q) fetch_unit(so_, t, q);
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < RU; ++k) fetch_r((uint32_t)(row0(0) * a.F), 0, k);
+        }
     }
     wait_vmcnt<(AHEAD - 1) * UPW>();
     __syncthreads();
@@ -1037,7 +1134,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
             }
         }
     }
-    if constexpr (!OUT_BF16) f8_atomic_amax(&a.st->amax[a.t_out], amax);
+    if constexpr (!OUT_BF16) f8_atomic_amax(&a.st->amax[a.t_out], fmaxf(amax, fmaxf(amax2[0], amax2[1])));
 }
 
 template <int MODE, bool OUT_BF16>

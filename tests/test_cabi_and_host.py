@@ -196,6 +196,17 @@ def test_no_buffer_store_is_followed_by_a_write_of_its_data_registers():
         assert out.stdout.strip().startswith("0 unprotected"), out.stdout[-500:]
 
 
+def test_pinned_mfmas_keep_their_wait_states():
+    """The 8-bit weight-stationary kernels (csrc/fp8.cuh: gemm_ws8_kernel, gemm_wsd8_kernel) issue their MFMAs as volatile asm statements so
+    that the previous tile's epilogue can be paced between them; hipcc's hazard tables do not see inside such a statement.
+    tools/pinned_mfma_audit.py reads the device assembly: no vector write of an operand within two states in front of a pinned MFMA, no
+    vector write of a C operand that is not the destination within seven states behind it, no scratch in those kernels."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pinned_mfma_audit.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    first = out.stdout.strip().split("\n")[0]
+    assert first.endswith("0 finding(s)") and int(first.split()[0]) >= 6, out.stdout[-500:]
+
+
 def test_no_getenv_on_a_launch_path():
     """the product library never reads the environment (a call's settings travel in its cp_config); the tools-only build reads it
     once, when it is loaded, to seed the variant switches (csrc/api.hip, seed_variants_from_env, under #ifdef CP_VARIANTS)"""

@@ -1,10 +1,24 @@
 """Inline-assembly MFMAs are invisible to hipcc's hazard tables (cdna_hip_programming.md 5.7 item 2).  This scan of the device assembly
 checks, for every v_mfma_scale inside an ASMSTART/ASMEND pair, that (a) none of the two instructions in front of it is a vector
 instruction writing one of its VGPR operands (two wait states), (b) where its C operand is not its destination, no vector instruction
-writes C within the seven states behind it (the MFMA is still reading it), and (c) the kernel has no scratch.  usage: python tools/pinned_mfma_audit.py build/api.s [kernel-name-regex]
+writes C within the seven states behind it (the MFMA is still reading it), and (c) the kernel has no scratch.
+usage: python tools/pinned_mfma_audit.py [file.s] [kernel-name-regex]   (without a file: compiles csrc/api.hip to assembly first)
 Exit code 1 on a finding (a CPU test runs it on the product build's assembly)."""
+import os
 import re
+import subprocess
 import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def assembly_file(tmp):
+    out = os.path.join(tmp, "api.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w",
+                    os.path.join(ROOT, "contrastiveprosthetics_amd", "csrc", "api.hip"), "-o", out], check=True, cwd=tmp,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out
 
 
 def regs(tok):
@@ -83,7 +97,10 @@ def audit(path, pat):
 
 
 if __name__ == '__main__':
-    n, f = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else '.')
+    args = sys.argv[1:]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = args.pop(0) if args and args[0].endswith('.s') else assembly_file(tmp)
+        n, f = audit(path, args[0] if args else '.')
     print('%d kernel(s) with pinned MFMAs, %d finding(s)' % (n, len(f)))
     for x in f:
         print('  ' + x)
