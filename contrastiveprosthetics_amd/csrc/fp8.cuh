@@ -186,6 +186,10 @@ __global__ __launch_bounds__(256) void fold_linear8_batch_kernel(Fold8Batch fb, 
 //     once at the end (per tile: two VALU instructions per output, no cross-lane traffic);
 //   * the outputs of a sample tile leave as one 16-byte store per lane: the four feature tiles' dwords (4 features each) are
 //     transposed over the four lanes that hold one sample (v_permlane32_swap, v_permlane16_swap), 16 rows x 64 bytes per store.
+//   * the previous tile's epilogue is PACED between the MFMAs of the k loop: micro-operations of 3-5 vector instructions, each a volatile
+//     asm statement, behind MFMAs that are volatile asm statements themselves (up to four vector instructions hide
+//     behind one MX MFMA; hipcc's own schedule clustered both kinds).  tools/pinned_mfma_audit.py checks the wait states hipcc no
+//     longer sees.  (Measured and not kept: the MFMA groups that lead a fetch left empty of micro-operations -- 51.2 / 50.5 us either way.)
 // LDS image of a tile: row r at r*K, its 16-byte chunks XOR-swizzled with (r & 15) inside 256-byte groups (applied on the DMA's
 // per-lane source), so the 16 rows of a fragment read fall on 16 different chunk positions.
 // ------------------------------------------------------------------------------------------------------------------------
