@@ -1781,9 +1781,9 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             // BatchNorm-backward sums (gemm_tn.cuh, proj_wgrad_sums_kernel); on the critical path -- the data gradient below needs the sums
             if constexpr (sizeof(T) == 2) {
                 ProjWgradArgs pa{};
-                pa.dz = (const bf16_t*)dz; pa.R = act(8); pa.slabs = slabs; pa.M = N; pa.rows_per_split = ta.rows_per_split;
+                pa.dz = (const bf16_t*)dz; pa.R = act(8); pa.slabs = slabs; pa.M = N; pa.rows_per_split = ta.rows_per_split; pa.splits = S;
                 pa.dp_thresh = dp_thresh(c->dp_emg); pa.dp_key = dp_key(c, 8); pa.dp_salt = dp_salt(c);
-                hipLaunchKernelGGL(proj_wgrad_sums_kernel<false>, dim3(4, S), dim3(256), 0, st, pa);
+                hipLaunchKernelGGL(proj_wgrad_sums_kernel<false>, dim3(PROJ_WGRAD_GRID(S)), dim3(256), 0, st, pa);
                 CKL("proj_wgrad_sums_kernel");
                 hipLaunchKernelGGL(proj_wgrad_finish_kernel, dim3(32, PROJ_FINISH_ROWS), dim3(256), 0, st, slabs, S, stats(8) + 2 * 512, stats(8) + 3 * 512, p->last_w,
                                    dp_inv_keep(c->dp_emg), (const int*)nullptr, g->last_w, partials);
@@ -2068,9 +2068,9 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         if (drop) {
             // (encoder_backward_t: one pass over r8 for the weight gradient AND fc7's BatchNorm-backward sums, on the critical path)
             ProjWgradArgs pa{};
-            pa.dz = (const bf16_t*)dz; pa.R = base + w.act8[8]; pa.slabs = slabs; pa.M = N; pa.rows_per_split = ta.rows_per_split;
+            pa.dz = (const bf16_t*)dz; pa.R = base + w.act8[8]; pa.slabs = slabs; pa.M = N; pa.rows_per_split = ta.rows_per_split; pa.splits = S;
             pa.dp_thresh = dp_thresh(c->dp_emg); pa.dp_key = dp_key(c, 8); pa.dp_salt = dp_salt(c);
-            hipLaunchKernelGGL(proj_wgrad_sums_kernel<true>, dim3(4, S), dim3(256), 0, st, pa);
+            hipLaunchKernelGGL(proj_wgrad_sums_kernel<true>, dim3(PROJ_WGRAD_GRID(S)), dim3(256), 0, st, pa);
             CKL("proj_wgrad_sums_kernel<e4m3>");
             hipLaunchKernelGGL(proj_wgrad_finish_kernel, dim3(32, PROJ_FINISH_ROWS), dim3(256), 0, st, slabs, S, stats(8) + 2 * 512, stats(8) + 3 * 512, p->last_w,
                                dp_inv_keep(c->dp_emg), (const int*)&fs->e[F8_T_ACT + 8], g->last_w, partials);
