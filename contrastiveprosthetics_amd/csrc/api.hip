@@ -187,7 +187,7 @@ struct WS {
     size_t partials_floats, slabs_floats;
 };
 static const size_t kSlabFloats = (size_t)64 * 512 * 512 + 1024;   // 64 splits of a 512x512 (or 40 of a 512x768) f32 slab
-static const int kHeadBlocksMax = 1024;
+static const int kHeadBlocksMax = 1024;          // (512 / 256 measured: 44.4 / 54.1 us against 43.6)
 static const int kSumSlices = 16;           // row slices (= partial rows) of bn_bwd_sums_from_wgrad_kernel
 
 static WS carve(int64_t N, int dtype, float dp) {
@@ -346,7 +346,7 @@ extern "C" int cp_gather_groups(const float* table, int64_t table_rows, const in
                                 const int64_t* perm, int64_t B, int32_t V, float* x_out, void* stream) {
     if (!table || !emg_rand || !perm || !x_out || B <= 0 || V <= 0) return fail(CP_ERR_ARG, "cp_gather_groups args");
     const int64_t total = B * CP_TASKS * V * 3;
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);      // (caps 1024 / 512 measured: 10.7 / 11.8 us against 10.7)
     ProfScope ps(CP_K_GATHER, (hipStream_t)stream);
     hipLaunchKernelGGL(gather_groups_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, table, emg_rand, perm, x_out,
                        B, CP_TASKS, (int)V, D, table_rows);
@@ -366,6 +366,16 @@ extern "C" int cp_gather_oob_count(uint32_t* count_out, int32_t reset, void* str
 // ---------------------------------------------------------------------------------------
 // encoder forward
 // ---------------------------------------------------------------------------------------
+// Workgroup caps of the streaming passes around a dropout (bn_dropout_apply[8], bn_relu_bwd[8]).  Round 4, third part: 512 = two
+// workgroups per CU.  With 4,096 / 2,048 a thread saw five / ten rows -- one batch of four loads in flight and a tail -- behind a
+// prologue of 32 statistics loads; at 512 it walks 41 rows in batches of four.  Same box, traced steps, caps 256 / 384 / 512 / 768 /
+// 1024 / 1536 / (4096 | 2048): bn_dropout_apply8 45 / 46 / 38-39 / 38 / 40 / 40 / 56-60 us, bn_relu_bwd8 53 / 46 / 43 / 44 / 49 / 57 / 54-57,
+// bn_dropout_apply (bf16) 76 / 64 / 57-58 / 58-59 / 60 / 59 / 60, bn_relu_bwd 98 / 85 / 87 / 86-88 / 95 / 88 / 88-89 (the 16-bit passes
+// were at the copy rate already).  The 8-bit step: 2,424-2,467 -> 2,315-2,354 us.
+#define CAP_BDA16 512
+#define CAP_BDA8 512
+#define CAP_BRB16 512
+#define CAP_BRB8 512
 static inline int grid_rows(int64_t rows, int rows_per_block, int cap) {
     int64_t g = (rows + rows_per_block - 1) / rows_per_block;
     return (int)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -531,7 +541,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
     // conv1
     {
         constexpr int RPP = 256 / (64 / D::EPC);                      // windows per block and pass
-        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;          // (caps 1024 / 512 measured: 23.6 / 23.8 us against 20.6)
         const int g = (int)((need + passes - 1) / passes);            // every block makes the same number of passes
         if (batch_stats) {                               // (evaluation with running statistics needs nothing of conv1 but its recomputation)
             ProfScope ps(CP_K_CONV1_FWD, st);
@@ -562,7 +572,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         if (drop && Lp >= 5) {
             T* u = (T*)(base + w.u[Lp - 5]);
             ProfScope ps(CP_K_DROPOUT, st);
-            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N, 256 / (512 / D::EPC), 4096)), dim3(256), 0, st,
+            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N, 256 / (512 / D::EPC), CAP_BDA16)), dim3(256), 0, st,
                                act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c));
             CKL("bn_dropout_apply_kernel");
             A = u; s = nullptr; t = nullptr;
@@ -612,7 +622,7 @@ static int encoder_forward_t(const cp_config* c, const cp_params* p, const cp_bn
         if (drop && !fused_u8) {
             T* u = (T*)(base + w.u[Lp - 5]);
             ProfScope ps(CP_K_DROPOUT, st);
-            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N, 256 / (512 / D::EPC), 4096)), dim3(256), 0, st,
+            hipLaunchKernelGGL((bn_dropout_apply_kernel<T>), dim3(grid_rows(N, 256 / (512 / D::EPC), CAP_BDA16)), dim3(256), 0, st,
                                act(Lp), stats(Lp), u, N, 512, dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c));
             CKL("bn_dropout_apply_kernel");
             A = u;
@@ -697,7 +707,7 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
     // conv1 (statistics only) and conv2 (output as e4m3)
     {
         constexpr int RPP = 256 / (64 / D::EPC);
-        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;          // (caps 1024 / 512 measured: 23.6 / 23.8 us against 20.6)
         const int g = (int)((need + passes - 1) / passes);
         if (batch_stats) {
             ProfScope ps(CP_K_CONV1_FWD, st);
@@ -742,7 +752,7 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
             uint8_t* u = base + w.u8[Lp - 5];
             t_in = F8_T_U + (Lp - 5);
             ProfScope ps(CP_K_DROPOUT, st);
-            hipLaunchKernelGGL(bn_dropout_apply8_kernel, dim3(grid_rows(N, 256 / (512 / 16), 4096)), dim3(256), 0, st, A, stats(Lp), u, N, 512,
+            hipLaunchKernelGGL(bn_dropout_apply8_kernel, dim3(grid_rows(N, 256 / (512 / 16), CAP_BDA8)), dim3(256), 0, st, A, stats(Lp), u, N, 512,
                                dp_thresh(c->dp_emg), dp_key(c, Lp), dp_inv_keep(c->dp_emg), dp_salt(c), fs, F8_T_ACT + Lp, t_in);
             CKL("bn_dropout_apply8_kernel");
             A = u; s = nullptr; t = nullptr;
@@ -843,7 +853,7 @@ static int encoder_forward_small_t(const cp_config* c, const cp_params* p, const
     };
     {
         constexpr int RPP = 256 / (64 / D::EPC);
-        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;
+        const int64_t need = (N + RPP - 1) / RPP, passes = (need + 2047) / 2048;          // (caps 1024 / 512 measured: 23.6 / 23.8 us against 20.6)
         const int g = (int)((need + passes - 1) / passes);
         ProfScope ps(CP_K_CONV1_FWD, st);
         hipLaunchKernelGGL((conv1_stats_kernel<T>), dim3(g), dim3(256), 0, st, x, p->conv1_w, p->conv1_b, partials, R12, acc_of(0));
@@ -1873,7 +1883,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             int nr = stat_rows;
             const float* pp = pre(nr, 2 * 512);
             if (int e = bwd_finalize(pp, nr, (double)N, L, 512, 1, "bn_bwd_finalize_kernel")) return e;
-            const int gb = grid_rows(N, 256 / (512 / D::EPC), 2048);
+            const int gb = grid_rows(N, 256 / (512 / D::EPC), CAP_BRB16);
             hipLaunchKernelGGL((bn_relu_bwd_kernel<T>), dim3(gb), dim3(256), 256 * D::EPC * 4, st, cur, act(L), coef, partials, N, 512);
             nr = gb;
             pp = pre(nr, 512);
@@ -2114,7 +2124,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             int nr = stat_rows;
             const float* pp = pre(nr, 2 * 512);
             if (int e = bwd_finalize(pp, nr, (double)N, L, 512, 1, "bn_bwd_finalize_kernel")) return e;
-            const int gb = grid_rows(N, 256 / (512 / 16), 2048);
+            const int gb = grid_rows(N, 256 / (512 / 16), CAP_BRB8);
             hipLaunchKernelGGL(bn_relu_bwd8_kernel, dim3(gb), dim3(256), 8 * 512 * 4, st, cur, base + w.act8[L], coef, partials, N, 512, fs,
                                F8_T_GB + L, F8_T_ACT + L, F8_T_GRAD + L);
             nr = gb;
