@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void bn_dropout_apply8_kernel(const uint8_t* _
         }
         *(uint4*)(u + m * C + f) = make_uint4(o[0], o[1], o[2], o[3]);
     };
-    // four rows in flight per thread (two were: 55-69 us for 172 MB, nowhere near the copy rate)
+    // four rows in flight per thread (two were: 55-69 us for 172 MB, nowhere near the copy rate; eight: no further gain on 512 workgroups)
     const int64_t step = (int64_t)gridDim.x * rpp;
     int64_t m = (int64_t)blockIdx.x * rpp + rr;
     for (; m + 3 * step < rows; m += 4 * step) {
@@ -1346,13 +1346,18 @@ __global__ __launch_bounds__(256) void bn_relu_bwd8_kernel(uint8_t* __restrict__
     };
     const int64_t step = (int64_t)gridDim.x * rpp;
     int64_t m = (int64_t)blockIdx.x * rpp + rr;
-    for (; m + step < rows; m += 2 * step) {
+    // four rows in flight per thread (two were, on four times the workgroups: round 4, third part -- api.hip CAP_BRB8)
+    for (; m + 3 * step < rows; m += 4 * step) {
         const uint4 g0 = *(const uint4*)(g + m * C + cc * 16), r0 = *(const uint4*)(r + m * C + cc * 16);
         const uint4 g1 = *(const uint4*)(g + (m + step) * C + cc * 16), r1 = *(const uint4*)(r + (m + step) * C + cc * 16);
+        const uint4 g2 = *(const uint4*)(g + (m + 2 * step) * C + cc * 16), r2 = *(const uint4*)(r + (m + 2 * step) * C + cc * 16);
+        const uint4 g3 = *(const uint4*)(g + (m + 3 * step) * C + cc * 16), r3 = *(const uint4*)(r + (m + 3 * step) * C + cc * 16);
         apply(g0, r0, m);
         apply(g1, r1, m + step);
+        apply(g2, r2, m + 2 * step);
+        apply(g3, r3, m + 3 * step);
     }
-    if (m < rows) apply(*(const uint4*)(g + m * C + cc * 16), *(const uint4*)(r + m * C + cc * 16), m);
+    for (; m < rows; m += step) apply(*(const uint4*)(g + m * C + cc * 16), *(const uint4*)(r + m * C + cc * 16), m);
     const float un = f8_exp2i(-e_o);
 #pragma unroll
     for (int e = 0; e < 16; ++e) dyn_red[rr * C + cc * 16 + e] = sum[e] * un;
