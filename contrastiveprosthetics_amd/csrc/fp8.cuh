@@ -1561,7 +1561,7 @@ __global__ __launch_bounds__(256, 2) void proj_dgrad8_kernel(Proj8Args a) {
 template <int PASS>
 static inline hipError_t launch_proj_dgrad8(const Proj8Args& a, hipStream_t st, int* stat_rows) {
     if (a.K < 16 || (a.K & 3) || !a.R || (PASS == 1 && !a.coef) || (uint64_t)a.M * 512 >= 0xFFF00000ull) return hipErrorInvalidValue;
-    const int blocks = 1024, nwk = (blocks >> 3) / 2;
+    const int blocks = PROJ_DGRAD_BLOCKS, nwk = (blocks >> 3) / 2;
     const int64_t tiles = (a.M + 31) / 32, workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
     hipLaunchKernelGGL(proj_dgrad8_kernel<PASS>, dim3(blocks), dim3(256), 0, st, a);

@@ -915,7 +915,10 @@ __global__ __launch_bounds__(256, 2) void proj_dgrad_kernel(GemmNTArgs a) {
 template <int PASS>
 static inline hipError_t launch_proj_dgrad(const GemmNTArgs& a, hipStream_t st, int* stat_rows) {
     if ((a.F & 255) || a.K < 16 || (a.K & 3) || !a.R || (PASS == 1 && !a.coef)) return hipErrorInvalidValue;
-    const int blocks = 1024, nwk = (blocks >> 3) / (a.F >> 8);
+// workgroups of the projection's data-gradient launches (this one and fp8.cuh's): two per CU.  1024 / 768 / 512 / 384 / 256 on one box:
+// 84-89 / 82-84 / 76-81 / 95 / 98 us (16-bit), 62-63 / 57 / 54-57 / 70 / 68 (8-bit)
+#define PROJ_DGRAD_BLOCKS 512
+    const int blocks = PROJ_DGRAD_BLOCKS, nwk = (blocks >> 3) / (a.F >> 8);
     const int64_t tiles = (a.M + PROJ_RT - 1) / PROJ_RT, workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
     hipLaunchKernelGGL(proj_dgrad_kernel<PASS>, dim3(blocks), dim3(256), 0, st, a);
