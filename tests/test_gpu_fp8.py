@@ -53,8 +53,10 @@ def e4m3(t):
     return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
 
 
-@pytest.mark.parametrize("B", [64, 3])
+@pytest.mark.parametrize("B", [64, 3, 210, 423])
 def test_fc_kernels_against_their_own_arithmetic(B):
+    # (210 / 423 groups = 8,610 / 17,343 rows: workers of the weight-stationary kernels with one, two and three tiles and a ragged last
+    #  one -- every branch of the paced epilogue's counted waits, round 4)
     adabn = False
     sd = nontrivial_sd(31, adabn)
     EMG = randn(501, (B, T, 1, 1, 12))
@@ -163,7 +165,7 @@ def test_step_runs_and_learns():
 
 
 @pytest.mark.parametrize("dp", [0.0, 0.0635])
-@pytest.mark.parametrize("B", [64, 5])
+@pytest.mark.parametrize("B", [64, 5, 210])
 def test_backward_8bit_against_the_bf16_bridge(dp, B):
     """the 8-bit backward kernels (e5m2 gradients, e4m3 activations and W^T) against the bf16 backward kernels run on the SAME
     forward pass's tensors (cp_config.options, CP_OPT_FP8_BRIDGE): every parameter gradient by cosine and by norm.  What separates the two is the
