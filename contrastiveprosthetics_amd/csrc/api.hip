@@ -1465,7 +1465,7 @@ static int glove_backward_t(const cp_config* c, const cp_glove_params* gp, int64
         ta.X = dzg; ta.ldx = 64; ta.Y = av; ta.ldy = GL_H; ta.slabs = slabs; ta.M = R; ta.P = 64; ta.Q = GL_H;
         split_rows(R, kGloveSlabs, &S, &ta.rows_per_split);
         CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, CP_D_E, (const float*)nullptr,
+        hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, CP_D_E, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, g->last_w, 0, (float*)nullptr);
         CKL("reduce_slabs(glove last)");
     }
@@ -1494,7 +1494,7 @@ static int glove_backward_t(const cp_config* c, const cp_glove_params* gp, int64
         ta.X = xp; ta.ldx = GL_KP; ta.Y = gbuf; ta.ldy = GL_H; ta.slabs = slabs; ta.M = R; ta.P = 64; ta.Q = GL_H;
         split_rows(R, kGloveSlabs, &S, &ta.rows_per_split);
         CK((launch_gemm_tn<T, 64, 128, YLOAD_PLAIN>(ta, S, st)));
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, GL_IN, (const float*)nullptr,
+        hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(32), dim3(256), 0, st, slabs, S, 64, GL_H, GL_IN, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, g->w1, 3, (float*)nullptr);
         CKL("reduce_slabs(glove w1)");
     }
@@ -1809,7 +1809,7 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
         }
         float* praw = (float*)(base + w.praw);
         if (!proj_alg) {
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
+            hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0,
                                drop ? (float*)nullptr : praw);
             CKL("reduce_slabs(last)");
         }
@@ -1938,12 +1938,12 @@ static int encoder_backward_t(const cp_config* c, const cp_params* p, const floa
             float* praw = (float*)(base + w.praw);
             if (pending) {
                 // the deferred layer (always behind a dropout: no BN fold to undo, no raw product wanted)
-                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, sw, wslabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
+                hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(512), dim3(256), 0, sw, wslabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
                                    (const float*)nullptr, (const float*)nullptr, g->fc_b[pend.i], g->fc_w[pend.i], 0, (float*)nullptr);
                 CKL("reduce_slabs(fc, deferred)");
                 pending = false;
             }
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, sw, wslabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
+            hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(512), dim3(256), 0, sw, wslabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
                                i == 0 ? 1 : 0, in_drop ? (float*)nullptr : praw);
             CKL("reduce_slabs(fc)");
             if (!in_drop) {
@@ -2087,7 +2087,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             CKL("proj_wgrad_finish_kernel");
         } else {
             CK((launch_gemm_tn<T, 64, 128, YLOAD_F8>(ta, S, sw)));
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0, praw,
+            hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(32), dim3(256), 0, sw, ta.slabs, S, 64, 512, CP_D_E, s, t, dzsum, g->last_w, 0, praw,
                                (const int*)nullptr, (const int*)nullptr);
             CKL("reduce_slabs(last)");
         }
@@ -2165,13 +2165,13 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
         if (!defer_wgrad) {
             ProfScope ps(CP_K_REDUCE_SLABS, sw);
             if (pending) {
-                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, sw, wslabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
+                hipLaunchKernelGGL(reduce_slabs_kernel<bf16_t>, dim3(512), dim3(256), 0, sw, wslabs + (size_t)32 * 512 * 512, S, 512, 512, 512,
                                    (const float*)nullptr, (const float*)nullptr, g->fc_b[pend.i], g->fc_w[pend.i], 0, (float*)nullptr,
                                    (const int*)&fs->e[pend.tx], (const int*)&fs->e[pend.ty]);
                 CKL("reduce_slabs(fc, deferred)");
                 pending = false;
             }
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(512), dim3(256), 0, sw, wslabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
+            hipLaunchKernelGGL(reduce_slabs_kernel<bf16_t>, dim3(512), dim3(256), 0, sw, wslabs, S, 512, K, 512, s, t, g->fc_b[i], g->fc_w[i],
                                i == 0 ? 1 : 0, in_drop ? (float*)nullptr : praw, (const int*)&fs->e[tx], (const int*)&fs->e[ty]);
             CKL("reduce_slabs(fc)");
             if (!in_drop) {

@@ -1277,7 +1277,11 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN8Args a) {
                 acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fx[i], fy[jj], acc[i][jj], 1, 0, 0, 127, 0, 127);
         __builtin_amdgcn_s_setprio(0);
     }
-    float* slab = (second ? a.slabs2 : a.slabs) + (int64_t)split * a.P * a.Q;
+    // The slabs of the 8-bit path are bf16 (round 4, third part): a partial sum over 2,624+ rows of products of e5m2 gradients carries the
+    // gradients' own quantisation noise, 2^-3 per element / sqrt(rows) ~ 2^-8.7, so eight mantissa bits round it at its noise level; the
+    // 64 (32) slabs are summed in f32 (reduce_slabs_kernel<bf16_t>).  Half the slab bytes written here and read there: this launch
+    // moves 316 MB at the copy rate, 66 of them slabs.  (The slab AREA keeps its f32 size and offsets.)
+    bf16_t* slab = (bf16_t*)(second ? a.slabs2 : a.slabs) + (int64_t)split * a.P * a.Q;
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1287,7 +1291,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN8Args a) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int p = p0 + wp * 128 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                slab[(int64_t)p * a.Q + q] = acc[i][jj][g];
+                slab[(int64_t)p * a.Q + q] = f2bf(acc[i][jj][g]);
             }
         }
 }
