@@ -61,7 +61,10 @@ def test_two_streams_compute_what_one_stream_does(dtype):
             assert torch.equal(v, one[k]), k                                # untouched by the re-pairing: bit for bit the one-stream result
         else:
             ref = one[k].double()
-            tol = 2e-2 if dtype == "fp8" else 2e-3                          # fc4's product carries the BatchNorm-backward sums of everything below
+            # fc4's product carries the BatchNorm-backward sums of everything below.  8 bits: the slabs of the weight-gradient products are
+            # bf16 since round 4's third part, and alone instead of paired means 64 partial sums per entry instead of 32 -- other roundings
+            # (measured: 2.02e-2 on conv2's bias gradient, the far end of the chain; 1e-2 with f32 slabs)
+            tol = 3e-2 if dtype == "fp8" else 2e-3
             assert float((v.double() - ref).norm()) <= tol * float(ref.norm()) + 1e-12, (k, k in resummed)
 
 
