@@ -702,6 +702,15 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
             ra.eps = c->bn_eps;
             hipLaunchKernelGGL(bn_running_stats_kernel, dim3(CP_N_BN), dim3(512), 0, st, ra);
         }
+        if (batch_stats && drop) {
+            // the folds of the layers behind a dropout (fc5..fc7: their operand is the dropout OUTPUT, no BatchNorm affine to fold) need
+            // nothing of this pass but the scale table: one launch here instead of three between the GEMMs
+            Fold8Batch fb{};
+            for (int i = 4; i < CP_N_FC; ++i)
+                fb.job[i - 4] = Fold8Job{p->fc_w[i], p->fc_b[i], nullptr, nullptr, base + w.wfc8[i], base + w.wsc8[i],
+                                         (float*)(base + w.bfc[i]), fcK(i), 0, F8_T_U + (i - 4), F8_T_ACT + 2 + i};
+            hipLaunchKernelGGL(fold_linear8_batch_kernel, dim3(512, CP_N_FC - 4), dim3(256), 0, st, fb, (const Fp8State*)fs);
+        }
         CKL("prep kernels (fp8)");
     }
     // conv1 (statistics only) and conv2 (output as e4m3)
@@ -757,7 +766,7 @@ static int encoder_forward_fp8(const cp_config* c, const cp_params* p, const cp_
             CKL("bn_dropout_apply8_kernel");
             A = u; s = nullptr; t = nullptr;
         }
-        if (batch_stats) {                 // (running statistics: all seven folds were made in one launch before the loop)
+        if (batch_stats && !in_drop) {     // (running statistics: all seven folds were made in one launch before the loop; behind a dropout: in the prep launch)
             ProfScope ps(CP_K_FOLD, st);
             hipLaunchKernelGGL(fold_linear8_kernel, dim3(512), dim3(256), 0, st, p->fc_w[i], p->fc_b[i], s, t, base + w.wfc8[i], base + w.wsc8[i],
                                (float*)(base + w.bfc[i]), K, i == 0 ? 1 : 0, fs, t_in, F8_T_ACT + L);
