@@ -134,6 +134,11 @@ def load():
         raise CpNativeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch first: its wheel carries its own HIP runtime (torch/lib/libamdhip64.so), and the process must end up with ONE runtime -- the
+    # one that owns torch's allocations and streams.  With libcpnative.so loaded first the dynamic loader binds it to /opt/rocm's copy,
+    # torch then brings its own, and every launch of this library fails with hipErrorNoDevice on the box (seen: build() and smoke() in
+    # one process).  Loaded behind torch, the library resolves against the runtime that is already there.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -295,3 +295,16 @@ def test_gather_counts_rows_outside_the_table():
     E.gather_groups(table, bad, perm, 1)
     assert E.gather_oob_count(reset=True) == 2
     assert E.gather_oob_count(reset=False) == 0
+
+
+def test_build_then_smoke_in_one_process():
+    """__graft_entry__.build() loads the library before anything imported torch; smoke() then runs on the same process.  torch's wheel carries
+    its own HIP runtime: with libcpnative.so dlopened first the process ended up with two and every launch of the library failed with
+    hipErrorNoDevice (round 4).  _lib.load() imports torch first now; this runs the driver's two hooks back to back in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
