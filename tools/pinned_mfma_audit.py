@@ -14,11 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def assembly_file(tmp):
-    out = os.path.join(tmp, "api.s")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w",
-                    os.path.join(ROOT, "contrastiveprosthetics_amd", "csrc", "api.hip"), "-o", out], check=True, cwd=tmp,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return out
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _device_asm import assembly_path          # compiled once into build/, reused while no source is newer
+    return assembly_path(False)
 
 
 def regs(tok):

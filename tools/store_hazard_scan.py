@@ -17,13 +17,9 @@ def assembly() -> str:
     args = [a for a in sys.argv[1:] if a != "--variants"]
     if args:
         return open(args[0]).read()
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "api.s")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"]
-                       + (["-DCP_VARIANTS"] if "--variants" in sys.argv else []) + [
-                        os.path.join(ROOT, "contrastiveprosthetics_amd", "csrc", "api.hip"), "-o", out], check=True, cwd=d,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        return open(out).read()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _device_asm import assembly_path          # compiled once into build/, reused while no source is newer
+    return open(assembly_path("--variants" in sys.argv)).read()
 
 
 def regs(tok: str):
