@@ -2207,7 +2207,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
                 ProfScope ps(Lp == 1 ? CP_K_FC_DGRAD_CONV : CP_K_FC_DGRAD_BN, st);
                 // (fc1's launch writes e5m2 like the others -- round 3's wrote 258 MB of bf16 for the conv kernels; they expand the bytes now)
                 a.C = Lp == 1 ? (void*)gconv : (void*)nxt; a.t_out = F8_T_GRAD + Lp;
-                CK((launch_gemm_wsd8<0, false>(a, st, &drows)));
+                CK((launch_gemm_wsd8<0>(a, st, &drows)));
                 if (Lp == 1) gcol_rows = drows;
             }
             {
@@ -2225,7 +2225,7 @@ static int encoder_backward_fp8(const cp_config* c, const cp_params* p, const fl
             a.R = base + w.u8[Lp - 5]; a.t_r = F8_T_U + (Lp - 5); a.bn_stats = stats(Lp); a.dp_inv_keep = dp_inv_keep(c->dp_emg);
             ProfScope ps(CP_K_FC_DGRAD_STATS, st);
             int drows = 0;
-            CK((launch_gemm_wsd8<1, false>(a, st, &drows)));
+            CK((launch_gemm_wsd8<1>(a, st, &drows)));
             stat_rows = drows;
         }
         if (aux.on && L >= 6) {

@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void transpose_w8_batch_kernel(Transpose8Batch
 // of the saved e4m3 activation R it needs (2 KiB, two LDS-DMA instructions) during the tile's own k loop and reads it back, in
 // the accumulator layout, in that tile's epilogue one k loop later (its own vmcnt is the only ordering).
 //   MODE 0: BatchNorm + ReLU backward of the layer below in the epilogue (coef), output = dL/d(its pre-activation), column sums =
-//           its bias gradient.  OUT_BF16: output stored as bf16 in true units (fc1's launch: the conv kernels read 16-bit gradients).
+//           its bias gradient.
 //   MODE 1: behind a dropout: R is the forward pass's dropout OUTPUT u = mask (s r + t) / (1 - p) (e4m3, stored for the weight
 //           gradient anyway): u != 0 IS the mask (no hash in the epilogue -- the first build recomputed it and spent 2.4x the matrix
 //           pipe's cycles in VALU), output = masked dL/d(BatchNorm output) (F8_T_GB), and the two BatchNorm-backward sums follow
@@ -759,12 +759,12 @@ struct Wsd8Args {
     const uint8_t* wsc;     // [F]
     const uint8_t* R;       // [M][F] e4m3: MODE 0 saved activation of the layer below, MODE 1 its dropout output u
     const float* bn_stats;  // MODE 1: [4][F] mean, invstd, scale s, shift t of the layer below (to turn sum g u into sum g r)
-    void* C;                // [M][F] e5m2 (or bf16 with OUT_BF16)
+    void* C;                // [M][F] e5m2
     float* partials;        // MODE 0: [workers][F] column sums (true units);  MODE 1: [workers][2][F]
     const float* coef;      // MODE 0: [3][coef_mod]
     int coef_mod;
     Fp8State* st;
-    int t_r, t_out;         // scale-table ids of R and of the output (t_out < 0 with OUT_BF16)
+    int t_r, t_out;         // scale-table ids of R and of the output
     int64_t M;
     int F;
     uint32_t dp_thresh, dp_key;
@@ -779,14 +779,13 @@ __device__ __forceinline__ f32x4_t mx_mfma_g(const i32x8_t& w, const i32x8_t& g,
 }
 
 #define WSD8_RT 32
-template <int MODE, bool OUT_BF16>
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
     f8_saturating_conversions();                       // (the e5m2 stores of the epilogue carry no clamp)
     constexpr bool STATS = MODE == 1;
     constexpr int K = 512, KB = K / 128, RT = WSD8_RT, ST = RT / 16, NBUF = 4, AHEAD = NBUF - 1;
     constexpr int TILE_BYTES = RT * K, UPW = TILE_BYTES / 1024 / 4, CPR = K / 16, R_BYTES = RT * 64, RU = R_BYTES / 1024;
     constexpr int R_OFF = NBUF * TILE_BYTES, RBUF = 3;
-    static_assert(!OUT_BF16, "the paced epilogue stores e5m2 (fc1's gradient into conv2 is e5m2 since round 4)");
     static_assert((AHEAD - 1) * UPW + AHEAD * (ST + RU) <= 63, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char smem[R_OFF + 4 * RBUF * R_BYTES];
 
@@ -802,7 +801,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
     const int ntile = (wkr < nwk && first < tiles) ? (int)((tiles - first + stride - 1) / stride) : 0;
     if (ntile == 0) return;
     const int f0 = fb * 256 + wave * 64;
-    const int e_r = a.st->e[a.t_r], e_o = OUT_BF16 ? 0 : a.st->e[a.t_out];
+    const int e_r = a.st->e[a.t_r], e_o = a.st->e[a.t_out];
     const float so = f8_exp2i(e_o);
     const float keep_so = a.dp_inv_keep * so;                                // MODE 1: 1 / (1 - p) and the output scale
 
@@ -875,18 +874,14 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
     for (int p = 0; p < 16; ++p) s1[p] = 0.f;
 #pragma unroll
     for (int p = 0; p < (STATS ? 16 : 1); ++p) s2[p] = 0.f;
-    constexpr int OB = OUT_BF16 ? 2 : 1;                                     // bytes per output element
-    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * a.F * OB), 0x00020000);
-    // e5m2: after the 4-lane transpose a lane owns features q4*16 .. +15 of its sample (16 bytes); bf16: features foff .. foff + 7 of
-    // each 32-feature pair after one permlane16 swap (gemm_ws16_kernel)
-    const int foff = ((q4 & 1) << 4) | ((q4 >> 1) << 3);
-    const uint32_t c_lane = OUT_BF16 ? (uint32_t)(s16 * a.F + f0 + foff) * 2 : (uint32_t)(s16 * a.F + f0 + q4 * 16);
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)((int64_t)a.M * a.F), 0x00020000);
+    // after the 4-lane transpose a lane owns features q4*16 .. +15 of its sample (16 bytes)
+    const uint32_t c_lane = (uint32_t)(s16 * a.F + f0 + q4 * 16);
 
     auto epi_st = [&](f32x4_t (&old)[4][ST], const unsigned char* Rw, int st, uint32_t s_old, bool live, int64_t /*m_old*/) {
         const int row = st * 16 + s16;
         const int rsw = (row >> 2) & 3;
         uint32_t d[4];
-        uint2 pk[4];
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
             float rv[4];
@@ -906,17 +901,10 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
             }
             // (the sums are of the values AS STORED: the bias gradient and the BatchNorm-backward sums derived from it must describe
             //  the tensor the next kernels read)
-            if constexpr (OUT_BF16) {
-                pk[ft].x = cvt_pk_bf16<false>(y[0], y[1]);
-                pk[ft].y = cvt_pk_bf16<false>(y[2], y[3]);
-                y[0] = __uint_as_float(pk[ft].x << 16); y[1] = __uint_as_float(pk[ft].x & 0xffff0000u);
-                y[2] = __uint_as_float(pk[ft].y << 16); y[3] = __uint_as_float(pk[ft].y & 0xffff0000u);
-            } else {
-                amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
-                amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
-                d[ft] = f8_pack4_e5m2(y[0], y[1], y[2], y[3]);
-                f8_unpack4_e5m2(d[ft], y);
-            }
+            amax = fmaxf(fmaxf(amax, fabsf(y[0])), fabsf(y[1]));
+            amax = fmaxf(fmaxf(amax, fabsf(y[2])), fabsf(y[3]));
+            d[ft] = f8_pack4_e5m2(y[0], y[1], y[2], y[3]);
+            f8_unpack4_e5m2(d[ft], y);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float w = live ? y[e] : 0.f;
@@ -924,24 +912,13 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
                 if constexpr (STATS) s2[ft * 4 + e] = fmaf(w, rv[e], s2[ft * 4 + e]);
             }
         }
-        if constexpr (OUT_BF16) {
-#pragma unroll
-            for (int fp = 0; fp < 2; ++fp) {
-                const auto sx = __builtin_amdgcn_permlane16_swap(pk[2 * fp].x, pk[2 * fp + 1].x, false, false);
-                const auto sy = __builtin_amdgcn_permlane16_swap(pk[2 * fp].y, pk[2 * fp + 1].y, false, false);
-                const u32x4_t c = {sx[0], sy[0], sx[1], sy[1]};
-                store_b128_settled(c, c_rsrc, c_lane, (s_old + (uint32_t)(st * 16 * a.F + fp * 32)) * 2, 0);
-            }
-        } else {
-            { const auto x = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false); d[0] = x[0]; d[2] = x[1]; }
-            { const auto x = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false); d[1] = x[0]; d[3] = x[1]; }
-            { const auto x = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false); d[0] = x[0]; d[1] = x[1]; }
-            { const auto x = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false); d[2] = x[0]; d[3] = x[1]; }
-            const u32x4_t c = {d[0], d[1], d[2], d[3]};
-            store_b128_settled(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.F), 0);
-        }
+        { const auto x = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false); d[0] = x[0]; d[2] = x[1]; }
+        { const auto x = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false); d[1] = x[0]; d[3] = x[1]; }
+        { const auto x = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false); d[0] = x[0]; d[1] = x[1]; }
+        { const auto x = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false); d[2] = x[0]; d[3] = x[1]; }
+        const u32x4_t c = {d[0], d[1], d[2], d[3]};
+        store_b128_settled(c, c_rsrc, c_lane, s_old + (uint32_t)(st * 16 * a.F), 0);
     };
-    constexpr int NST = OUT_BF16 ? 2 * ST : ST;                              // stores per epilogue
 
     // fragment reads on four lane bases + immediates (gemm_ws8_kernel)
     uint32_t fro[2][2];
@@ -1138,16 +1115,16 @@ __global__ __launch_bounds__(256, 1) void gemm_wsd8_kernel(Wsd8Args a) {
             }
         }
     }
-    if constexpr (!OUT_BF16) f8_atomic_amax(&a.st->amax[a.t_out], fmaxf(amax, fmaxf(amax2[0], amax2[1])));
+    f8_atomic_amax(&a.st->amax[a.t_out], fmaxf(amax, fmaxf(amax2[0], amax2[1])));
 }
 
-template <int MODE, bool OUT_BF16>
+template <int MODE>
 static inline hipError_t launch_gemm_wsd8(const Wsd8Args& a, hipStream_t st, int* stat_rows) {
     if ((a.F & 255) || a.F > 768 || a.M <= 0 || (uint64_t)a.M * a.F >= 0xFFF00000ull || !a.R || (MODE == 0 && !a.coef)) return hipErrorInvalidValue;
     const int nwk = 32 / (a.F >> 8);
     const int64_t tiles = (a.M + WSD8_RT - 1) / WSD8_RT, workers = (int64_t)nwk * 8;
     if (stat_rows) *stat_rows = (int)(tiles < workers ? tiles : workers);
-    hipLaunchKernelGGL((gemm_wsd8_kernel<MODE, OUT_BF16>), dim3(256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_wsd8_kernel<MODE>), dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

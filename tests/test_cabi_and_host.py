@@ -173,14 +173,14 @@ def test_lr_closed_forms_equal_the_reference_schedulers(final_epochs):
 
 def test_register_stationary_gemm_kernel_has_no_spills():
     """The weight-stationary GEMM kernels (csrc/gemm_ws.cuh: gemm_ws16_kernel, gemm_ws16n_kernel, gemm_wsd16_kernel<0|1>; csrc/fp8.cuh:
-    gemm_ws8_kernel<512|768>, gemm_wsd8_kernel<0|1, .>) keep 128-256 weight registers per wave and run at the edge of the 512-register file.  A spill costs them their
+    gemm_ws8_kernel<512|768>, gemm_wsd8_kernel<0|1>) keep 128-256 weight registers per wave and run at the edge of the 512-register file.  A spill costs them their
     speed (scratch traffic inside the k loop), and in round 2 every build that spilled also returned wrong values -- that turned out to be
     the store-data hazard that csrc/gemm_ws.cuh::store_b128_settled now closes, not the spills themselves; the guard stays for the speed:
     hipcc's resource remarks are checked at build time."""
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh"), "gemm_wsd?(16n?|8)?_kernel"], capture_output=True, text=True,
                          check=True).stdout
     lines = [l for l in out.splitlines() if "gemm_ws" in l]
-    assert len(lines) >= 8, out          # (ws16, ws16n, wsd16<0|1>, ws8<512|768>, wsd8<0|1, false>)
+    assert len(lines) >= 8, out          # (ws16, ws16n, wsd16<0|1>, ws8<512|768>, wsd8<0|1>)
     for l in lines:
         assert re.search(r"spill\s+0\s+scratch\s+0\b", l), l
 
