@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void l2_sumsq_kernel(OptArgs a) {
     const int64_t base = (int64_t)(chunk - t.chunk0) * OPT_CHUNK;
     float s = 0.f;
     if (t.l2) {
-        if (((t.offset | t.numel) & 3) == 0) {
+        if (((t.offset | t.numel) & 3) == 0 && ((uintptr_t)a.p & 15) == 0) {
             // 16-byte loads where the tensor allows (every tensor of the model does): eight 4-byte loads per thread were the launch's time
             // (round 4, third part); the order of the additions per thread changes with it, the result stays run-to-run exact
             for (int i = threadIdx.x * 4; i < OPT_CHUNK; i += 1024) {
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void adam_kernel(OptArgs a) {
         v = a.beta2 * v + (1.f - a.beta2) * g * g;
         return p - step * (m / (sqrtf(v) * rs2 + a.eps));
     };
-    if (((t.offset | t.numel) & 3) == 0) {
+    if (((t.offset | t.numel) & 3) == 0 && ((((uintptr_t)a.p | (uintptr_t)a.g | (uintptr_t)a.m | (uintptr_t)a.v)) & 15) == 0) {
         // four elements per thread and load (element-wise: the same numbers as the scalar form)
         for (int i = threadIdx.x * 4; i < OPT_CHUNK; i += 1024) {
             const int64_t e = base + i;

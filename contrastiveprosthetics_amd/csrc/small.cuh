@@ -702,6 +702,19 @@ struct SmReduceJob { const float* slab; float* dst; int numel; };
 struct SmReduceBatch { SmReduceJob job[16]; int njobs, splits; int64_t slab_stride; };
 __global__ __launch_bounds__(256) void sm_reduce_grads_kernel(SmReduceBatch b) {
     const SmReduceJob jb = b.job[blockIdx.y];
+    // 16-byte loads and stores where the job allows (every tensor of the model does; round 4, third part: one element per thread and load
+    // was 12.6 us of a 260 us step); per element the same additions in the same order
+    if ((((uintptr_t)jb.slab | (uintptr_t)jb.dst) & 15) == 0 && ((jb.numel | b.slab_stride) & 3) == 0) {
+        for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < jb.numel; i += gridDim.x * 1024) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < b.splits; ++q) {
+                const float4 v = *(const float4*)(jb.slab + (int64_t)q * b.slab_stride + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *(float4*)(jb.dst + i) = s;
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.numel; i += gridDim.x * 256) {
         float s = 0.f;
         for (int q = 0; q < b.splits; ++q) s += jb.slab[(int64_t)q * b.slab_stride + i];
@@ -732,11 +745,35 @@ __global__ __launch_bounds__(256) void sm_prep_kernel(SmPrepBatch b) {
     const int y = blockIdx.y;
     if (y < b.njobs) {
         const SmCopyJob jb = b.job[y];
-        for (int j = blockIdx.x; j < jb.rows_out; j += SM_PREP_GX)
-            for (int kp = threadIdx.x; kp < jb.K; kp += 256) {
-                const int k = jb.mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;
-                D::store((T*)jb.out + (int64_t)j * jb.K + kp, j < jb.F ? jb.W[(int64_t)j * jb.K + k] : 0.f);
+        // one 16-byte chunk of the output (8 bf16 / 4 f32) per thread and pass (round 4, third part: one element per thread -- 2-byte stores
+        // in bf16 -- was most of this launch's 10 us); mode 1 gathers its chunk's elements from the reference's column order
+        constexpr int EPC = D::EPC;
+        const int cpr = jb.K / EPC;                        // chunks per row (K is a multiple of 64)
+        const int total = (((uintptr_t)jb.W | (uintptr_t)jb.out) & 15) == 0 ? jb.rows_out * cpr : 0;      // (a caller's unaligned tensors: element by element below)
+        if (total == 0)
+            for (int j = blockIdx.x; j < jb.rows_out; j += SM_PREP_GX)
+                for (int kp = threadIdx.x; kp < jb.K; kp += 256) {
+                    const int k = jb.mode == 1 ? (kp & 63) * 12 + (kp >> 6) : kp;
+                    D::store((T*)jb.out + (int64_t)j * jb.K + kp, j < jb.F ? jb.W[(int64_t)j * jb.K + k] : 0.f);
+                }
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < total; c += SM_PREP_GX * 256) {
+            const int j = c / cpr, kp = (c % cpr) * EPC;
+            float v[EPC];
+            if (j >= jb.F) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+            } else if (jb.mode == 1) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = jb.W[(int64_t)j * jb.K + ((kp + e) & 63) * 12 + ((kp + e) >> 6)];
+            } else {
+#pragma unroll
+                for (int q = 0; q < EPC / 4; ++q) {
+                    const float4 w = *(const float4*)(jb.W + (int64_t)j * jb.K + kp + 4 * q);
+                    v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+                }
             }
+            *(uint4*)((T*)jb.out + (int64_t)j * jb.K + kp) = D::pack(v);
+        }
     } else if (y == b.njobs) {                              // the step's BatchNorm accumulators (forward and backward) start at zero
         for (int i = blockIdx.x * 256 + threadIdx.x; i < b.nzero; i += SM_PREP_GX * 256) b.zero[i] = 0;
     } else if (y <= b.njobs + b.ntrans) {
