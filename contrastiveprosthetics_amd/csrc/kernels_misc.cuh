@@ -511,8 +511,17 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ partials, in
                                           float* __restrict__ db) {
     const int tid = threadIdx.x;                       // 256 threads: (k, c)
     const int k = tid >> 6, c = tid & 63;
+    // rows in order, loads eight deep (one row per round trip: 9.3 us for <= 512 rows)
     double s = 0;
-    for (int r = 0; r < nrows; ++r) s += (double)partials[((int64_t)r * 4 + k) * 64 + c];
+    int r = 0;
+    for (; r + 8 <= nrows; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partials[((int64_t)(r + u) * 4 + k) * 64 + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; r < nrows; ++r) s += (double)partials[((int64_t)r * 4 + k) * 64 + c];
     if (k < 3) {
         dW[c * 9 + 3 + k] = (float)s;
         dW[c * 9 + 0 + k] = 0.f;
